@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MCTS node-evaluations per second on the chess 20x256 network, batch 256.
+
+One "step" = one pass of the leaf-evaluation hot path over one batch of 256 synthetic leaf
+positions: bitboard planes (already resident in HBM) -> plane-pack -> 41 fused 3x3 conv+BN+ReLU
+launches -> policy/value heads -> logits + values in HBM.  ``value`` is leaves evaluated per
+second summed over all ranks (weak scaling: every GPU runs its own batch stream, as self-play
+games shard across GPUs with no collective on the evaluation path).
+
+    python bench.py                       # 1 GPU, defaults
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on
+    "chess20x256": dict(game="chess", blocks=20, filters=256, vhc=8, phc=8, batch=256, seed=2),
+    # configs[1] and configs[4], selectable for extra measurements
+    "hex7_6x64": dict(game="hex7", blocks=6, filters=64, vhc=16, phc=16, batch=128, seed=1),
+    "chess40x384": dict(game="chess", blocks=40, filters=384, vhc=8, phc=8, batch=512, seed=3),
+}
+
+
+def make_workload(name: str):
+    from cattus_amd import synth
+    from cattus_amd.weights import CHESS, NetDesc, hex_game, seeded_blob
+
+    w = WORKLOADS[name]
+    if w["game"] == "chess":
+        d = NetDesc(**CHESS, blocks=w["blocks"], filters=w["filters"], vhc=w["vhc"], phc=w["phc"])
+        planes = synth.random_chess_planes(w["batch"], w["seed"])
+    else:
+        d = NetDesc(**hex_game(7), blocks=w["blocks"], filters=w["filters"], vhc=w["vhc"], phc=w["phc"])
+        planes = synth.random_hex_planes(w["batch"], 7, w["seed"])
+    return d, seeded_blob(d, w["seed"]), planes
+
+
+def cpu_baseline(blob, planes, budget_s: float = 20.0):
+    """The oracle (a plain C port of the same arithmetic) timed on this host's cores, on a bounded
+    sample of the same workload."""
+    from oracle import oracle
+
+    net = oracle.OracleNet(blob)
+    threads = oracle.default_threads()
+    n = min(len(planes), threads)
+    t0 = time.perf_counter()
+    net.forward(planes[:n], threads=threads)
+    dt = time.perf_counter() - t0
+    # second, larger sample sized to the remaining budget
+    n2 = int(min(len(planes), max(n, (budget_s - dt) * n / dt * 0.8)))
+    n2 = max(threads, n2 // threads * threads)
+    t0 = time.perf_counter()
+    net.forward(planes[:n2], threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n2 / dt,
+        "unit": "node-evals/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n2} of the {len(planes)} bench leaves, oracle/oracle_net.c f32 on {threads} threads, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="chess20x256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the leaf evaluator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cattus_amd.evaluator import HipEvaluator
+
+    d, blob, planes = make_workload(args.workload)
+    batch = len(planes)
+    plane_words = planes.shape[2]
+    ev = HipEvaluator(blob, batch_size=batch, plane_words=plane_words, dtype=args.dtype, device=local_rank)
+
+    dev = torch.device("cuda", local_rank)
+    d_planes = torch.from_numpy(planes.view(np.int64)).to(dev)
+    d_policy = torch.empty((batch, d.moves), dtype=torch.float32, device=dev)
+    d_value = torch.empty((batch,), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ev.eval_device(d_planes.data_ptr(), batch, d_policy.data_ptr(), d_value.data_ptr(), stream.cuda_stream)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the timed kernels produced real numbers
+    assert bool(torch.isfinite(d_policy).all()) and bool(torch.isfinite(d_value).all())
+
+    if rank == 0:
+        value = world * batch * args.steps / elapsed
+        # roofline of the dominant kernel (3x3 conv tower launch), timed live with HIP events
+        launch_us, launches = ev.time_tower(batch, 10)
+        flop_per_launch = d.conv_flops_per_position() * batch / launches
+        achieved = flop_per_launch / (launch_us * 1e-6) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        out = {
+            "metric": "MCTS node-evals/sec (chess 20x256 net, batch 256)",
+            "value": value,
+            "unit": "node-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic leaf positions + seeded random-init weights",
+            "config": {
+                "workload": f"{args.workload}: ConvNetV1 {d.blocks}x{d.filters}, board {d.board}, "
+                f"{d.planes} planes, {d.moves} moves, batch {batch} leaves/GPU, evaluator-only",
+                "per_gpu_batch": batch,
+                "flop_per_leaf": d.flops_per_position(),
+            },
+            "per_gpu_value": value / world,
+            "roofline": {
+                "kernel": "conv3x3_mfma_kernel",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                "traffic": None,
+                "avg_launch_us": launch_us,
+                "launches_per_step": launches,
+                "flop_per_launch": flop_per_launch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(blob, planes)
+        print(json.dumps(out), flush=True)
+
+    ev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""In-tree native builds (hipcc cross-compiles gfx950 without a GPU present)."""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+ROOT = PKG.parent
+
+HIP_LIB = PKG / "libcattus_hip.so"
+HIP_SOURCES = [CSRC / "kernels.hip", CSRC / "evaluator.hip"]
+HIP_DEPS = HIP_SOURCES + [CSRC / "kernels.h", ROOT / "include" / "cattus_hip.h"]
+
+# -ffp-contract=off: the f32 path promises a fixed fmaf-chain order, so the compiler
+# must not fuse or split any multiply-add on its own, on the device or in the host-side BN folding.
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-ffp-contract=off",
+    "-fvisibility=hidden",
+    "-Wall",
+    "-Wno-unused-result",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: the HIP evaluator cannot be built")
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> Path:
+    """Compile cattus_amd/libcattus_hip.so for gfx950."""
+    if force or _stale(HIP_LIB, HIP_DEPS):
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-o", str(HIP_LIB), *map(str, HIP_SOURCES), "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force=True, verbose=True)

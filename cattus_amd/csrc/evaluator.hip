@@ -1,0 +1,678 @@
+// Host side of libcattus_hip.so: the C ABI declared in include/cattus_hip.h.
+//
+// Replaces NNetwork::run_net + Model::{new,run} (reference: engine/src/net/mod.rs:41-72,
+// engine/src/net/model.rs:61-218) and Batcher::apply (engine/src/util/batch.rs:49-177).
+// There is deliberately no CPU fallback: without a usable HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/cattus_hip.h"
+#include "kernels.h"
+
+using namespace cattus;
+
+#define CATTUS_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t err__ = (expr);                                                                      \
+        if (err__ != hipSuccess)                                                                        \
+            return fail(CATTUS_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr size_t HEADER_BYTES = 64;
+constexpr float BN_EPS = 1e-5f;
+constexpr uint32_t FC_HIDDEN = 128;
+
+inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // keep NaN a NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+// BatchNorm (eval) folded into the preceding bias-free conv:
+//   scale = gamma / sqrtf(var + eps);  w' = w * scale;  b' = beta - mean * scale
+// (gamma = 1, beta = 0 where the reference builds BatchNorm2d(affine=False): net_utils.py:14,30,68,78).
+// This file is compiled with -ffp-contract=off: the products and the subtraction round separately.
+struct Folded {
+    std::vector<float> w;  // [taps][cout][cin]
+    std::vector<float> b;  // [cout]
+};
+
+Folded fold_conv(const float* w, uint32_t cout, uint32_t cin, uint32_t taps, const float* gamma, const float* beta,
+                 const float* mean, const float* var) {
+    Folded f;
+    f.w.resize((size_t)taps * cout * cin);
+    f.b.resize(cout);
+    for (uint32_t co = 0; co < cout; co++) {
+        const float g = gamma ? gamma[co] : 1.0f;
+        const float be = beta ? beta[co] : 0.0f;
+        const float scale = g / sqrtf(var[co] + BN_EPS);
+        f.b[co] = be - mean[co] * scale;
+        for (uint32_t ci = 0; ci < cin; ci++)
+            for (uint32_t t = 0; t < taps; t++)
+                f.w[((size_t)t * cout + co) * cin + ci] = w[((size_t)co * cin + ci) * taps + t] * scale;
+    }
+    return f;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        if (p) (void)hipFree(p), p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) return fail(CATTUS_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return CATTUS_OK;
+    }
+    int upload(const void* src, size_t bytes) {
+        int rc = alloc(bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return CATTUS_OK;
+    }
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct PinnedBuf {
+    void* p = nullptr;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    int alloc(size_t bytes) {
+        hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(CATTUS_E_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return CATTUS_OK;
+    }
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct ConvLayer {
+    DevBuf w, b;
+    uint32_t cin = 0;  // as laid out on the device (padded for the MFMA path)
+};
+
+struct ServerBatch {
+    uint64_t seq = 0;
+    uint32_t count = 0, collected = 0;
+    bool sealed = false, done = false;
+    int status = CATTUS_OK;
+    std::string error;
+    std::chrono::steady_clock::time_point t0;
+    std::vector<uint64_t> planes;
+    std::vector<float> policy, value;
+};
+
+}  // namespace
+
+struct cattus_eval {
+    cattus_net_desc d{};
+    cattus_eval_config cfg{};
+    bool tuned = false;  // MFMA NHWC tower vs generic NCHW f32 tower
+    Act act = Act::F32;
+    uint32_t hw = 0, bpad = 0, cpad0 = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    ConvLayer stem;
+    std::vector<std::unique_ptr<ConvLayer>> c1, c2;
+    DevBuf head_w, head_b, w1t, b1, w2, b2, wpt, bp;
+
+    DevBuf d_planes, x0, a, t, y, hv, h1, d_policy, d_value;
+    PinnedBuf h_planes, h_policy, h_value;
+
+    std::mutex run_mu;  // serialises use of the activation buffers / stream
+    std::mutex stat_mu;
+    cattus_stats stats{};
+
+    // leaf server
+    std::mutex srv_mu;
+    std::condition_variable srv_cv, done_cv;
+    std::deque<std::unique_ptr<ServerBatch>> batches;  // oldest first; back() is collecting unless sealed
+    uint64_t next_seq = 1;
+    bool flush_req = false, stop = false;
+    std::thread server;
+
+    ~cattus_eval() {
+        {
+            std::lock_guard<std::mutex> lk(srv_mu);
+            stop = true;
+        }
+        srv_cv.notify_all();
+        done_cv.notify_all();
+        if (server.joinable()) server.join();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+size_t blob_floats(const cattus_net_desc& d) {
+    const size_t hw = (size_t)d.board * d.board, F = d.filters;
+    size_t n = F * d.planes * 9 + 4 * F;
+    n += (size_t)d.blocks * (2 * F * F * 9 + 6 * F);
+    n += (size_t)d.vhc * F + 2 * (size_t)d.vhc + (size_t)FC_HIDDEN * d.vhc * hw + FC_HIDDEN + FC_HIDDEN + 1;
+    n += (size_t)d.phc * F + 2 * (size_t)d.phc + (size_t)d.moves * d.phc * hw + d.moves;
+    return n;
+}
+
+// Upload one folded 3x3 layer in the layout of the selected tower.
+int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, uint32_t cin) {
+    int rc;
+    if ((rc = L.b.upload(f.b.data(), cout * sizeof(float)))) return rc;
+    if (!e->tuned) {
+        L.cin = cin;
+        return L.w.upload(f.w.data(), f.w.size() * sizeof(float));
+    }
+    const uint32_t kc = (uint32_t)act_kc(e->act);
+    const uint32_t cpad = (cin + kc - 1) / kc * kc;
+    L.cin = cpad;
+    if (e->act == Act::BF16) {
+        std::vector<uint16_t> w((size_t)9 * cout * cpad, 0);
+        for (uint32_t t = 0; t < 9; t++)
+            for (uint32_t co = 0; co < cout; co++)
+                for (uint32_t ci = 0; ci < cin; ci++)
+                    w[((size_t)t * cout + co) * cpad + ci] = f32_to_bf16(f.w[((size_t)t * cout + co) * cin + ci]);
+        return L.w.upload(w.data(), w.size() * 2);
+    }
+    std::vector<float> w((size_t)9 * cout * cpad, 0.0f);
+    for (uint32_t t = 0; t < 9; t++)
+        for (uint32_t co = 0; co < cout; co++)
+            memcpy(&w[((size_t)t * cout + co) * cpad], &f.w[((size_t)t * cout + co) * cin], cin * sizeof(float));
+    return L.w.upload(w.data(), w.size() * 4);
+}
+
+int build(cattus_eval* e, const float* p) {
+    const cattus_net_desc& d = e->d;
+    const uint32_t F = d.filters, hw = e->hw;
+    auto take = [&](size_t n) {
+        const float* r = p;
+        p += n;
+        return r;
+    };
+    int rc;
+    {
+        const float* w = take((size_t)F * d.planes * 9);
+        const float *g = take(F), *be = take(F), *mu = take(F), *var = take(F);
+        if ((rc = upload_conv(e, e->stem, fold_conv(w, F, d.planes, 9, g, be, mu, var), F, d.planes))) return rc;
+        e->cpad0 = e->stem.cin;
+    }
+    for (uint32_t i = 0; i < d.blocks; i++) {
+        e->c1.emplace_back(new ConvLayer);
+        e->c2.emplace_back(new ConvLayer);
+        const float* w1 = take((size_t)F * F * 9);
+        const float *mu1 = take(F), *var1 = take(F);
+        if ((rc = upload_conv(e, *e->c1.back(), fold_conv(w1, F, F, 9, nullptr, nullptr, mu1, var1), F, F))) return rc;
+        const float* w2 = take((size_t)F * F * 9);
+        const float *g2 = take(F), *be2 = take(F), *mu2 = take(F), *var2 = take(F);
+        if ((rc = upload_conv(e, *e->c2.back(), fold_conv(w2, F, F, 9, g2, be2, mu2, var2), F, F))) return rc;
+    }
+    // heads: value rows first, then policy rows, in one [vhc+phc][F] 1x1 conv
+    std::vector<float> hw_w((size_t)(d.vhc + d.phc) * F), hw_b(d.vhc + d.phc);
+    const float* vw = take((size_t)d.vhc * F);
+    const float *vmu = take(d.vhc), *vvar = take(d.vhc);
+    Folded fv = fold_conv(vw, d.vhc, F, 1, nullptr, nullptr, vmu, vvar);
+    const float* fc1_w = take((size_t)FC_HIDDEN * d.vhc * hw);
+    const float* fc1_b = take(FC_HIDDEN);
+    const float* fc2_w = take(FC_HIDDEN);
+    const float* fc2_b = take(1);
+    const float* pw = take((size_t)d.phc * F);
+    const float *pmu = take(d.phc), *pvar = take(d.phc);
+    Folded fp = fold_conv(pw, d.phc, F, 1, nullptr, nullptr, pmu, pvar);
+    const float* pfc_w = take((size_t)d.moves * d.phc * hw);
+    const float* pfc_b = take(d.moves);
+    memcpy(hw_w.data(), fv.w.data(), fv.w.size() * 4);
+    memcpy(hw_w.data() + fv.w.size(), fp.w.data(), fp.w.size() * 4);
+    memcpy(hw_b.data(), fv.b.data(), fv.b.size() * 4);
+    memcpy(hw_b.data() + fv.b.size(), fp.b.data(), fp.b.size() * 4);
+    if ((rc = e->head_w.upload(hw_w.data(), hw_w.size() * 4))) return rc;
+    if ((rc = e->head_b.upload(hw_b.data(), hw_b.size() * 4))) return rc;
+
+    const uint32_t kv = d.vhc * hw, kp = d.phc * hw;
+    std::vector<float> w1t((size_t)kv * FC_HIDDEN), wpt((size_t)kp * d.moves);
+    for (uint32_t j = 0; j < FC_HIDDEN; j++)
+        for (uint32_t k = 0; k < kv; k++) w1t[(size_t)k * FC_HIDDEN + j] = fc1_w[(size_t)j * kv + k];
+    for (uint32_t m = 0; m < d.moves; m++)
+        for (uint32_t k = 0; k < kp; k++) wpt[(size_t)k * d.moves + m] = pfc_w[(size_t)m * kp + k];
+    if ((rc = e->w1t.upload(w1t.data(), w1t.size() * 4))) return rc;
+    if ((rc = e->b1.upload(fc1_b, FC_HIDDEN * 4))) return rc;
+    if ((rc = e->w2.upload(fc2_w, FC_HIDDEN * 4))) return rc;
+    if ((rc = e->b2.upload(fc2_b, 4))) return rc;
+    if ((rc = e->wpt.upload(wpt.data(), wpt.size() * 4))) return rc;
+    if ((rc = e->bp.upload(pfc_b, d.moves * 4))) return rc;
+
+    // activations
+    const size_t bp_ = e->bpad, B = e->cfg.max_batch;
+    const size_t esz = e->tuned ? (size_t)act_bytes(e->act) : 4;
+    const size_t slots = e->tuned ? SLOTS : hw;
+    if ((rc = e->d_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
+    if ((rc = e->x0.alloc(bp_ * slots * e->cpad0 * esz))) return rc;
+    if ((rc = e->a.alloc(bp_ * slots * F * esz))) return rc;
+    if ((rc = e->t.alloc(bp_ * slots * F * esz))) return rc;
+    if ((rc = e->y.alloc(bp_ * slots * F * esz))) return rc;
+    if ((rc = e->hv.alloc(bp_ * (kv + kp) * 4))) return rc;
+    if ((rc = e->h1.alloc(bp_ * FC_HIDDEN * 4))) return rc;
+    if ((rc = e->d_policy.alloc(B * d.moves * 4))) return rc;
+    if ((rc = e->d_value.alloc(B * 4))) return rc;
+    if ((rc = e->h_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
+    if ((rc = e->h_policy.alloc(B * d.moves * 4))) return rc;
+    if ((rc = e->h_value.alloc(B * 4))) return rc;
+    return CATTUS_OK;
+}
+
+struct TowerTimer {
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t used = 0;
+};
+
+// Enqueue the whole forward for n leaves whose planes are at d_planes; logits/values go to
+// d_policy/d_value.  With `tt`, a HIP event pair brackets every tower conv launch.
+int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float* d_policy, float* d_value,
+                    hipStream_t st, TowerTimer* tt = nullptr) {
+    const cattus_net_desc& d = e->d;
+    const uint32_t F = d.filters, hw = e->hw, S = d.board, w64 = e->cfg.plane_words;
+    auto mark = [&](bool begin) {
+        if (!tt) return;
+        if (begin && tt->used + 2 > tt->ev.size()) return;
+        (void)hipEventRecord(tt->ev[tt->used++], st);
+    };
+    void *a = e->a.p, *t = e->t.p, *y = e->y.p;
+    uint32_t nb = n;
+    if (e->tuned) {
+        nb = (n + BOARDS_PER_WG - 1) / BOARDS_PER_WG * BOARDS_PER_WG;
+        launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, e->x0.p, st);
+        mark(true);
+        launch_conv3x3_mfma(e->act, e->x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, F, S, st);
+        mark(false);
+        for (uint32_t i = 0; i < d.blocks; i++) {
+            mark(true);
+            launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, F, F, S, st);
+            mark(false);
+            mark(true);
+            launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, F, F, S, st);
+            mark(false);
+            std::swap(a, y);
+        }
+    } else {
+        launch_planes_to_tensor_nchw(d_planes, n, d.planes, w64, S, n, e->x0.as<float>(), st);
+        mark(true);
+        launch_conv3x3_generic(e->x0.as<float>(), e->stem.w.as<float>(), e->stem.b.as<float>(), nullptr, (float*)a, n,
+                               d.planes, F, S, st);
+        mark(false);
+        for (uint32_t i = 0; i < d.blocks; i++) {
+            mark(true);
+            launch_conv3x3_generic((float*)a, e->c1[i]->w.as<float>(), e->c1[i]->b.as<float>(), nullptr, (float*)t, n, F,
+                                   F, S, st);
+            mark(false);
+            mark(true);
+            launch_conv3x3_generic((float*)t, e->c2[i]->w.as<float>(), e->c2[i]->b.as<float>(), (float*)a, (float*)y, n,
+                                   F, F, S, st);
+            mark(false);
+            std::swap(a, y);
+        }
+    }
+    TowerView tv;
+    tv.x = a;
+    if (e->tuned) {
+        tv.act = e->act, tv.sb = SLOTS * F, tv.sk = 1, tv.sp = F;
+    } else {
+        tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;
+    }
+    const uint32_t kv = d.vhc * hw, kp = d.phc * hw;
+    launch_head_conv1x1(tv, e->head_w.as<float>(), e->head_b.as<float>(), n, F, d.vhc + d.phc, hw, e->hv.as<float>(), st);
+    launch_value_fc1(e->hv.as<float>(), kv + kp, e->w1t.as<float>(), e->b1.as<float>(), n, kv, e->h1.as<float>(), st);
+    launch_value_fc2_tanh(e->h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
+    launch_policy_fc(e->hv.as<float>(), kv + kp, kv, e->wpt.as<float>(), e->bp.as<float>(), n, kp, d.moves, d_policy, st);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(CATTUS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
+    return CATTUS_OK;
+}
+
+void account(cattus_eval* e, uint32_t n, double seconds) {
+    std::lock_guard<std::mutex> lk(e->stat_mu);
+    cattus_stats& s = e->stats;
+    // RunningAverage (reference: engine/src/util/metric.rs:1-20): first sample seeds the average
+    s.run_seconds_ema = s.batches == 0 ? seconds : 0.99 * s.run_seconds_ema + 0.01 * seconds;
+    s.run_seconds_total += seconds;
+    s.batches += 1;
+    s.positions += n;
+    if (n == e->cfg.max_batch) s.full_batches += 1;
+}
+
+// Blocking host-buffer evaluation; caller holds no lock.
+int eval_host(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy, float* value) {
+    const cattus_net_desc& d = e->d;
+    std::lock_guard<std::mutex> lk(e->run_mu);
+    HIP_TRY(hipSetDevice(e->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t pbytes = (size_t)n * d.planes * e->cfg.plane_words * 8;
+    memcpy(e->h_planes.p, planes, pbytes);
+    HIP_TRY(hipMemcpyAsync(e->d_planes.p, e->h_planes.p, pbytes, hipMemcpyHostToDevice, e->stream));
+    int rc = enqueue_forward(e, e->d_planes.as<uint64_t>(), n, e->d_policy.as<float>(), e->d_value.as<float>(), e->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_policy.p, e->d_policy.p, (size_t)n * d.moves * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_value.p, e->d_value.p, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(policy, e->h_policy.p, (size_t)n * d.moves * 4);
+    memcpy(value, e->h_value.p, (size_t)n * 4);
+    account(e, n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return CATTUS_OK;
+}
+
+ServerBatch* new_batch(cattus_eval* e) {
+    auto b = std::make_unique<ServerBatch>();
+    b->seq = e->next_seq++;
+    b->planes.resize((size_t)e->cfg.max_batch * e->d.planes * e->cfg.plane_words);
+    e->batches.push_back(std::move(b));
+    return e->batches.back().get();
+}
+
+void server_loop(cattus_eval* e) {
+    std::unique_lock<std::mutex> lk(e->srv_mu);
+    for (;;) {
+        // pick the oldest batch that is sealed and not yet run; seal the collecting one on deadline/flush
+        ServerBatch* run = nullptr;
+        for (auto& b : e->batches)
+            if (b->sealed && !b->done) {
+                run = b.get();
+                break;
+            }
+        if (!run && !e->batches.empty()) {
+            ServerBatch* cur = e->batches.back().get();
+            if (!cur->sealed && cur->count > 0) {
+                const auto deadline = cur->t0 + std::chrono::microseconds(e->cfg.flush_us);
+                if (e->flush_req || std::chrono::steady_clock::now() >= deadline) {
+                    cur->sealed = true;
+                    run = cur;
+                } else if (!e->stop) {
+                    e->srv_cv.wait_until(lk, deadline);
+                    continue;
+                }
+            }
+        }
+        if (!run) {
+            e->flush_req = false;
+            if (e->stop) return;
+            e->srv_cv.wait(lk);
+            continue;
+        }
+        const uint32_t n = run->count;
+        run->policy.resize((size_t)n * e->d.moves);
+        run->value.resize(n);
+        lk.unlock();
+        const int rc = eval_host(e, run->planes.data(), n, run->policy.data(), run->value.data());
+        std::string err = rc ? g_last_error : std::string();
+        lk.lock();
+        run->status = rc;
+        run->error = err;
+        run->done = true;
+        e->done_cv.notify_all();
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ ABI
+
+CATTUS_API const char* cattus_hip_last_error(void) { return g_last_error.c_str(); }
+CATTUS_API const char* cattus_hip_version(void) { return "cattus_hip 0.1 (gfx950)"; }
+
+CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattus_eval_config* cfg, cattus_eval** out) {
+    if (!out) return fail(CATTUS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!weights || !cfg) return fail(CATTUS_E_INVALID, "weights/cfg is NULL");
+    if (cfg->struct_size != sizeof(cattus_eval_config)) return fail(CATTUS_E_INVALID, "cfg.struct_size mismatch");
+    if (nbytes < HEADER_BYTES || memcmp(weights, "CATTUSW1", 8) != 0) return fail(CATTUS_E_INVALID, "not a cattus weight blob");
+    uint32_t h[9];
+    memcpy(h, (const char*)weights + 8, sizeof h);
+    if (h[0] != 1 || h[8] != FC_HIDDEN) return fail(CATTUS_E_INVALID, "unsupported blob version %u / hidden %u", h[0], h[8]);
+    cattus_net_desc d{h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]};
+    if (d.board < 1 || d.board > 11 || !d.planes || !d.filters || !d.vhc || !d.phc || !d.moves)
+        return fail(CATTUS_E_INVALID, "bad network shape in blob header");
+    if (nbytes != HEADER_BYTES + 4 * blob_floats(d)) return fail(CATTUS_E_INVALID, "blob size %zu does not match its header", nbytes);
+    if (cfg->max_batch < 1 || cfg->max_batch > (1u << 20)) return fail(CATTUS_E_INVALID, "max_batch out of range");
+    if ((uint64_t)cfg->plane_words * 64 < (uint64_t)d.board * d.board || cfg->plane_words > 2)
+        return fail(CATTUS_E_INVALID, "plane_words %u cannot hold a %ux%u board", cfg->plane_words, d.board, d.board);
+    if (d.planes * cfg->plane_words > 128) return fail(CATTUS_E_UNSUPPORTED, "more than 128 plane words per leaf");
+    if (cfg->dtype != CATTUS_DTYPE_F32 && cfg->dtype != CATTUS_DTYPE_BF16) return fail(CATTUS_E_INVALID, "unknown dtype %u", cfg->dtype);
+    if ((size_t)d.phc * d.board * d.board * 8 * 4 > 64 * 1024) return fail(CATTUS_E_UNSUPPORTED, "policy head too wide for the FC kernel");
+
+    int ndev = 0;
+    hipError_t herr = hipGetDeviceCount(&ndev);
+    if (herr != hipSuccess || ndev <= 0)
+        return fail(CATTUS_E_DEVICE, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(herr));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(CATTUS_E_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
+    if (!e) return fail(CATTUS_E_NOMEM, "out of memory");
+    e->d = d;
+    e->cfg = *cfg;
+    if (e->cfg.flush_us == 0) e->cfg.flush_us = 200;
+    e->device = cfg->device;
+    e->hw = d.board * d.board;
+    e->tuned = d.board <= 8 && d.filters % COUT_PER_WG == 0;
+    e->act = cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16 : Act::F32;
+    if (!e->tuned && e->act == Act::BF16)
+        return fail(CATTUS_E_UNSUPPORTED, "bf16 tower needs filters %% 64 == 0 and board <= 8 (got %u filters, board %u)", d.filters, d.board);
+    e->bpad = (cfg->max_batch + BOARDS_PER_WG - 1) / BOARDS_PER_WG * BOARDS_PER_WG;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    int rc = build(e.get(), reinterpret_cast<const float*>((const char*)weights + HEADER_BYTES));
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    {
+        std::lock_guard<std::mutex> lk(e->srv_mu);
+        new_batch(e.get());
+    }
+    e->server = std::thread(server_loop, e.get());
+    *out = e.release();
+    return CATTUS_OK;
+}
+
+CATTUS_API void cattus_hip_destroy(cattus_eval* e) { delete e; }
+
+CATTUS_API int cattus_hip_desc(const cattus_eval* e, cattus_net_desc* out) {
+    if (!e || !out) return fail(CATTUS_E_INVALID, "NULL argument");
+    *out = e->d;
+    return CATTUS_OK;
+}
+
+CATTUS_API int cattus_hip_eval(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy, float* value) {
+    if (!e || !planes || !policy || !value) return fail(CATTUS_E_INVALID, "NULL argument");
+    // planes_to_tensor asserts 1 <= n <= batch_size (engine/src/net/mod.rs:122-127)
+    if (n < 1 || n > e->cfg.max_batch) return fail(CATTUS_E_INVALID, "invalid sample len %u, 1..=%u", n, e->cfg.max_batch);
+    return eval_host(e, planes, n, policy, value);
+}
+
+CATTUS_API int cattus_hip_eval_device(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float* d_policy, float* d_value,
+                                      void* stream) {
+    if (!e || !d_planes || !d_policy || !d_value) return fail(CATTUS_E_INVALID, "NULL argument");
+    if (n < 1 || n > e->cfg.max_batch) return fail(CATTUS_E_INVALID, "invalid sample len %u, 1..=%u", n, e->cfg.max_batch);
+    std::lock_guard<std::mutex> lk(e->run_mu);
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    int rc = enqueue_forward(e, d_planes, n, d_policy, d_value, st);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> sl(e->stat_mu);
+    e->stats.batches += 1;
+    e->stats.positions += n;
+    if (n == e->cfg.max_batch) e->stats.full_batches += 1;
+    return CATTUS_OK;
+}
+
+CATTUS_API int cattus_hip_submit(cattus_eval* e, const uint64_t* planes_one, uint64_t* ticket) {
+    if (!e || !planes_one || !ticket) return fail(CATTUS_E_INVALID, "NULL argument");
+    const size_t words = (size_t)e->d.planes * e->cfg.plane_words;
+    std::unique_lock<std::mutex> lk(e->srv_mu);
+    if (e->stop) return fail(CATTUS_E_STATE, "evaluator is shutting down");
+    ServerBatch* cur = e->batches.back().get();
+    if (cur->sealed) cur = new_batch(e);
+    const uint32_t slot = cur->count++;
+    if (slot == 0) cur->t0 = std::chrono::steady_clock::now();
+    memcpy(cur->planes.data() + slot * words, planes_one, words * 8);
+    *ticket = (cur->seq << 32) | slot;
+    const bool full = cur->count == e->cfg.max_batch;
+    if (full) {
+        cur->sealed = true;
+        new_batch(e);
+    }
+    lk.unlock();
+    if (full || slot == 0) e->srv_cv.notify_one();
+    return CATTUS_OK;
+}
+
+CATTUS_API int cattus_hip_wait(cattus_eval* e, uint64_t ticket, float* policy, float* value) {
+    if (!e || !policy || !value) return fail(CATTUS_E_INVALID, "NULL argument");
+    const uint64_t seq = ticket >> 32;
+    const uint32_t slot = (uint32_t)ticket;
+    std::unique_lock<std::mutex> lk(e->srv_mu);
+    for (;;) {
+        ServerBatch* b = nullptr;
+        for (auto& x : e->batches)
+            if (x->seq == seq) {
+                b = x.get();
+                break;
+            }
+        if (!b || slot >= b->count) return fail(CATTUS_E_STATE, "unknown or already collected ticket %llu", (unsigned long long)ticket);
+        if (b->done) {
+            if (b->status != CATTUS_OK) {
+                g_last_error = b->error;
+                return b->status;
+            }
+            memcpy(policy, b->policy.data() + (size_t)slot * e->d.moves, (size_t)e->d.moves * 4);
+            *value = b->value[slot];
+            if (++b->collected == b->count) {
+                for (auto it = e->batches.begin(); it != e->batches.end(); ++it)
+                    if (it->get() == b) {
+                        e->batches.erase(it);
+                        break;
+                    }
+            }
+            return CATTUS_OK;
+        }
+        if (e->stop) return fail(CATTUS_E_STATE, "evaluator is shutting down");
+        e->done_cv.wait(lk);
+    }
+}
+
+CATTUS_API int cattus_hip_flush(cattus_eval* e) {
+    if (!e) return fail(CATTUS_E_INVALID, "NULL argument");
+    {
+        std::lock_guard<std::mutex> lk(e->srv_mu);
+        e->flush_req = true;
+    }
+    e->srv_cv.notify_one();
+    return CATTUS_OK;
+}
+
+CATTUS_API int cattus_hip_stats(cattus_eval* e, cattus_stats* out) {
+    if (!e || !out) return fail(CATTUS_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(e->stat_mu);
+    *out = e->stats;
+    return CATTUS_OK;
+}
+
+CATTUS_API int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, float* avg_launch_us, uint32_t* launches) {
+    if (!e || !avg_launch_us || !launches) return fail(CATTUS_E_INVALID, "NULL argument");
+    if (n < 1 || n > e->cfg.max_batch || reps < 1) return fail(CATTUS_E_INVALID, "bad n/reps");
+    std::lock_guard<std::mutex> lk(e->run_mu);
+    HIP_TRY(hipSetDevice(e->device));
+    const uint32_t per_fwd = 1 + 2 * e->d.blocks;
+    TowerTimer tt;
+    tt.ev.resize((size_t)2 * per_fwd);
+    for (auto& ev : tt.ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipMemsetAsync(e->d_planes.p, 0x5a, (size_t)n * e->d.planes * e->cfg.plane_words * 8, e->stream));
+    double total_ms = 0;
+    int rc = CATTUS_OK;
+    for (uint32_t rep = 0; rep < reps + 1 && rc == CATTUS_OK; rep++) {  // first pass is warm-up
+        tt.used = 0;
+        rc = enqueue_forward(e, e->d_planes.as<uint64_t>(), n, e->d_policy.as<float>(), e->d_value.as<float>(), e->stream, &tt);
+        if (rc) break;
+        hipError_t err = hipStreamSynchronize(e->stream);
+        if (err != hipSuccess) {
+            rc = fail(CATTUS_E_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(err));
+            break;
+        }
+        if (rep == 0) continue;
+        for (size_t i = 0; i + 1 < tt.used; i += 2) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, tt.ev[i], tt.ev[i + 1]);
+            total_ms += ms;
+        }
+    }
+    for (auto& ev : tt.ev) (void)hipEventDestroy(ev);
+    if (rc) return rc;
+    *launches = per_fwd;
+    *avg_launch_us = (float)(total_ms * 1000.0 / ((double)reps * per_fwd));
+    return CATTUS_OK;
+}
+
+CATTUS_API int cattus_hip_planes_to_tensor_device(const uint64_t* d_planes, uint32_t n, uint32_t C, uint32_t plane_words,
+                                                  uint32_t S, uint32_t batch, float* d_out, void* stream) {
+    if (!d_planes || !d_out) return fail(CATTUS_E_INVALID, "NULL argument");
+    if (n < 1 || n > batch) return fail(CATTUS_E_INVALID, "invalid sample len %u, 1..=%u", n, batch);
+    if (S < 1 || S > 11 || plane_words * 64 < S * S || !C) return fail(CATTUS_E_INVALID, "bad plane geometry");
+    launch_planes_to_tensor_nchw(d_planes, n, C, plane_words, S, batch, d_out, (hipStream_t)stream);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(CATTUS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
+    return CATTUS_OK;
+}
+
+CATTUS_API int cattus_hip_planes_to_tensor(int device, const uint64_t* planes, uint32_t n, uint32_t C, uint32_t plane_words,
+                                           uint32_t S, uint32_t batch, float* out) {
+    if (!planes || !out) return fail(CATTUS_E_INVALID, "NULL argument");
+    if (n < 1 || n > batch) return fail(CATTUS_E_INVALID, "invalid sample len %u, 1..=%u", n, batch);
+    if (S < 1 || S > 11 || plane_words * 64 < S * S || !C) return fail(CATTUS_E_INVALID, "bad plane geometry");
+    int ndev = 0;
+    hipError_t herr = hipGetDeviceCount(&ndev);
+    if (herr != hipSuccess || device < 0 || device >= ndev)
+        return fail(CATTUS_E_DEVICE, "no usable HIP device %d (%s); this library has no CPU path", device, hipGetErrorString(herr));
+    HIP_TRY(hipSetDevice(device));
+    DevBuf dp, dout;
+    int rc;
+    const size_t pbytes = (size_t)n * C * plane_words * 8, obytes = (size_t)batch * C * S * S * 4;
+    if ((rc = dp.upload(planes, pbytes))) return rc;
+    if ((rc = dout.alloc(obytes))) return rc;
+    rc = cattus_hip_planes_to_tensor_device(dp.as<uint64_t>(), n, C, plane_words, S, batch, dout.as<float>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, dout.p, obytes, hipMemcpyDeviceToHost));
+    return CATTUS_OK;
+}

@@ -1,0 +1,58 @@
+// Internal launch interface between evaluator.hip (host logic) and kernels.hip (gfx950 kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cattus {
+
+constexpr int SLOTS = 64;        // pixel slots per board in the tower layout (board edge <= 8)
+constexpr int BOARDS_PER_WG = 4; // boards per workgroup of the tower conv kernel
+constexpr int COUT_PER_WG = 64;  // output channels per workgroup of the tower conv kernel
+
+// Activation element of the tuned tower: 2-byte bf16 or 4-byte f32.
+enum class Act : int { F32 = 0, BF16 = 1 };
+
+inline int act_bytes(Act a) { return a == Act::BF16 ? 2 : 4; }
+// Input channels consumed per pipeline stage: one 128-byte LDS row.
+inline int act_kc(Act a) { return 128 / act_bytes(a); }
+
+// ---- K0: bitboard planes -> tensors -------------------------------------------------------
+// NHWC tower input [bpad][64][cpad] (rows >= n, slots >= S*S and channels >= C are zero).
+void launch_pack_planes_nhwc(Act act, const uint64_t* planes, uint32_t n, uint32_t bpad, uint32_t C,
+                             uint32_t w64, uint32_t S, uint32_t cpad, void* out, hipStream_t st);
+// Reference layout: f32 NCHW [batch][C][S*S], rows >= n zero (engine/src/net/mod.rs:121-156).
+void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C, uint32_t w64, uint32_t S,
+                                  uint32_t batch, float* out, hipStream_t st);
+
+// ---- K1/K2: 3x3 conv + folded BN (+ residual) + ReLU, MFMA, NHWC -------------------------
+// in [bpad][64][cin], w [9][cout][cin], bias [cout] f32, res/out [bpad][64][cout].
+// Requires bpad % 4 == 0, cin % kc == 0, cout % 64 == 0, S <= 8.
+void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
+                         uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st);
+
+// Generic f32 NCHW direct conv for shapes the MFMA kernel does not cover (any S <= 11, any C).
+// in [b][cin][hw], w [9][cout][cin], out [b][cout][hw]; same summation order as the MFMA f32 kernel.
+void launch_conv3x3_generic(const float* in, const float* w, const float* bias, const float* res, float* out,
+                            uint32_t b, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st);
+
+// ---- K3-K5: heads (f32 accumulate, k-ascending fmaf chains) -------------------------------
+// Tower output addressing: element (b, k, p) at  x[b*sb + k*sk + p*sp]  (elements of type `act`).
+struct TowerView {
+    const void* x;
+    Act act;
+    uint32_t sb, sk, sp;
+};
+// hv[b][(oc)*hw + p] = relu(sum_k w[oc][k]*x(b,k,p) + bias[oc]) for oc < ocn (value rows first, then policy)
+void launch_head_conv1x1(TowerView x, const float* w, const float* bias, uint32_t b, uint32_t F, uint32_t ocn,
+                         uint32_t hw, float* hv, hipStream_t st);
+// h1[b][j] = relu(sum_k w1t[k][j]*hv[b*hv_stride + k] + b1[j]), j < 128
+void launch_value_fc1(const float* hv, uint32_t hv_stride, const float* w1t, const float* b1, uint32_t b, uint32_t K,
+                      float* h1, hipStream_t st);
+// value[b] = tanh(sum_j w2[j]*h1[b][j] + b2)
+void launch_value_fc2_tanh(const float* h1, const float* w2, const float* b2, uint32_t b, float* value,
+                           hipStream_t st);
+// policy[b][m] = scrub(sum_k wpt[k][m]*hv[b*hv_stride + off + k] + bp[m])
+void launch_policy_fc(const float* hv, uint32_t hv_stride, uint32_t off, const float* wpt, const float* bp, uint32_t b,
+                      uint32_t K, uint32_t M, float* policy, hipStream_t st);
+
+}  // namespace cattus

@@ -1,0 +1,550 @@
+// gfx950 (MI355X / CDNA4) kernels of the Cattus leaf evaluator.
+//
+//   K0  pack_planes_nhwc / planes_to_tensor_nchw   bitboards -> tensors      (HBM-bound)
+//   K1  conv3x3_mfma<T, RES>                       3x3 conv + folded BN (+skip) + ReLU (MFMA-bound)
+//   K1g conv3x3_generic                            same arithmetic, any shape, SIMT f32
+//   K3  head_conv1x1, K4 value_fc1 / value_fc2_tanh, K5 policy_fc
+//
+// Arithmetic the kernels reproduce: ConvNetV1.forward in eval mode
+// (reference: training/cattus_train/net_utils.py:4-89) on the tensor planes_to_tensor builds
+// (reference: engine/src/net/mod.rs:121-156).  In f32 mode every output is an in-order fmaf
+// chain (v_mfma_f32_32x32x2_f32 chains k in issue order), in the order documented in DESIGN.md,
+// so results are bit-identical across batch sizes, batch compositions and to the CPU oracle.
+#include "kernels.h"
+
+namespace cattus {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ------------------------------------------------------------------------------------------
+// K0: plane expansion
+// ------------------------------------------------------------------------------------------
+
+// One workgroup per board: the board's C*w64 plane words are staged in LDS, then every thread
+// writes 16-byte channel vectors so that a wave stores 1 KiB contiguous.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_planes_nhwc_kernel(const uint64_t* __restrict__ planes, uint32_t n,
+                                                               uint32_t C, uint32_t w64, uint32_t hw, uint32_t cpad,
+                                                               T* __restrict__ out) {
+    constexpr uint32_t VEC = 16 / sizeof(T);
+    __shared__ uint64_t pl[128];
+    const uint32_t b = blockIdx.x;
+    const uint32_t words = C * w64;
+    for (uint32_t i = threadIdx.x; i < words; i += 256) pl[i] = b < n ? planes[(size_t)b * words + i] : 0ull;
+    __syncthreads();
+    const uint32_t groups = cpad / VEC;
+    T* ob = out + (size_t)b * SLOTS * cpad;
+    for (uint32_t v = threadIdx.x; v < SLOTS * groups; v += 256) {
+        const uint32_t q = v / groups, c0 = (v % groups) * VEC;
+        T vals[VEC];
+#pragma unroll
+        for (uint32_t i = 0; i < VEC; i++) {
+            const uint32_t c = c0 + i;
+            uint32_t bit = 0;
+            if (c < C && q < hw) bit = (uint32_t)(pl[c * w64 + (q >> 6)] >> (q & 63)) & 1u;
+            vals[i] = bit ? (T)1.0f : (T)0.0f;
+        }
+        *reinterpret_cast<f32x4*>(ob + (size_t)q * cpad + c0) = *reinterpret_cast<f32x4*>(vals);
+    }
+}
+
+// Reference layout (f32 NCHW).  Each thread produces four consecutive floats of the flat output.
+__global__ void __launch_bounds__(256) planes_to_tensor_nchw_kernel(const uint64_t* __restrict__ planes, uint32_t n,
+                                                                    uint32_t C, uint32_t w64, uint32_t hw,
+                                                                    uint64_t total, float* __restrict__ out) {
+    const uint64_t per_board = (uint64_t)C * hw;
+    for (uint64_t e0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; e0 < total; e0 += (uint64_t)gridDim.x * 1024) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t e = e0 + i;
+            float x = 0.0f;
+            if (e < total) {
+                const uint64_t b = e / per_board;
+                const uint32_t rem = (uint32_t)(e - b * per_board);
+                const uint32_t c = rem / hw, p = rem - c * hw;
+                if (b < n) x = (planes[(b * C + c) * w64 + (p >> 6)] >> (p & 63)) & 1ull ? 1.0f : 0.0f;
+            }
+            v[i] = x;
+        }
+        if (e0 + 4 <= total) {
+            *reinterpret_cast<f32x4*>(out + e0) = *reinterpret_cast<f32x4*>(v);
+        } else {
+            for (int i = 0; i < 4 && e0 + i < total; i++) out[e0 + i] = v[i];
+        }
+    }
+}
+
+void launch_pack_planes_nhwc(Act act, const uint64_t* planes, uint32_t n, uint32_t bpad, uint32_t C, uint32_t w64,
+                             uint32_t S, uint32_t cpad, void* out, hipStream_t st) {
+    if (act == Act::BF16)
+        hipLaunchKernelGGL(pack_planes_nhwc_kernel<__bf16>, dim3(bpad), dim3(256), 0, st, planes, n, C, w64, S * S, cpad,
+                           (__bf16*)out);
+    else
+        hipLaunchKernelGGL(pack_planes_nhwc_kernel<float>, dim3(bpad), dim3(256), 0, st, planes, n, C, w64, S * S, cpad,
+                           (float*)out);
+}
+
+void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C, uint32_t w64, uint32_t S,
+                                  uint32_t batch, float* out, hipStream_t st) {
+    const uint64_t total = (uint64_t)batch * C * S * S;
+    uint64_t blocks = (total + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride beyond that
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(planes_to_tensor_nchw_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, planes, n, C, w64, S * S,
+                       total, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: 3x3 conv as implicit GEMM on MFMA
+// ------------------------------------------------------------------------------------------
+//
+// out^T[cout][pixel] = sum_{chunk, tap, k} W[tap][cout][chunk*KC + k] * in[pixel + tap][chunk*KC + k]
+//
+// Workgroup = 4 waves = 4 boards x 64 output channels; wave w owns board w: a 64(cout) x 64(pixel)
+// tile = 2x2 MFMA 32x32 accumulators.  Weights are the MFMA A operand (row = cout), activations
+// the B operand (col = pixel), so each lane ends up with 4 consecutive couts of one pixel -> 8/16-byte
+// NHWC stores.
+//
+// K is walked as (chunk of one 128-byte row = KC channels) x (9 taps).  Per step one 8 KiB weight
+// slab [64 cout][128 B] is consumed; the 32 KiB activation chunk [4 boards][64 px][128 B] is loaded
+// once per chunk and re-read by all 9 taps with shifted pixel rows (out-of-board lanes read a zero
+// row), so activations cross L2->LDS once, not nine times.
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4): every step each wave issues exactly three 1 KiB
+// pieces (one activation piece of the NEXT chunk or a dummy, two weight pieces of step t+2 or
+// dummies), so a constant s_waitcnt vmcnt(3) retires everything step t needs.  LDS rows are
+// XOR-swizzled at 16-byte granularity (chunk ^ ((row>>1)&7)) on the global SOURCE side and on the
+// ds_read side; the DMA destination stays lane-linear.
+
+constexpr int LDS_ZERO = 0;                       // 128 B of zeros (padding rows)
+constexpr int LDS_ACT = 128;                      // 2 x 32 KiB
+constexpr int LDS_W = LDS_ACT + 2 * 32768;        // 3 x 8 KiB
+constexpr int LDS_SCRATCH = LDS_W + 3 * 8192;     // 4 x 1 KiB dummy DMA targets
+constexpr int LDS_TOTAL = LDS_SCRATCH + 4 * 1024; // 94336 B
+
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<__bf16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ void mac(const frag& a, const frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <>
+struct Mfma<float> {
+    typedef f32x4 frag;
+    // lane half h holds k = 4h + j in element j: the chain visits k = 0,4,1,5,2,6,3,7 of the 8-group
+    static __device__ __forceinline__ void mac(const frag& a, const frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
+}
+
+template <typename T, bool HAS_RES>
+__global__ void __launch_bounds__(256, 1)
+    conv3x3_mfma_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                        const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S) {
+    constexpr int KC = 128 / (int)sizeof(T);
+    typedef typename Mfma<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware block order: blocks with equal blockIdx % 8 share an L2, so give each such group a
+    // contiguous range of board groups (all cout blocks of a board group stay on one XCD).
+    const int nblk = gridDim.x, ncb = cout / COUT_PER_WG;
+    int logical = blockIdx.x;
+    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int cout0 = (logical % ncb) * COUT_PER_WG;
+    const int b0 = (logical / ncb) * BOARDS_PER_WG;
+
+    if (tid < 8) reinterpret_cast<f32x4*>(smem + LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nch = cin / KC;
+    const int T_total = nch * 9;
+    const size_t row_bytes = (size_t)cin * sizeof(T);
+
+    // ---- staging helpers (lane i of a DMA piece fills LDS row i>>3, 16-byte slot i&7) ----
+    const int prow = lane >> 3, pslot = lane & 7;
+    auto stage_w = [&](int t, int slot) {
+        const int ch = t / 9, tap = t - ch * 9;
+        const char* wb = reinterpret_cast<const char*>(w) + ((size_t)(tap * cout + cout0)) * row_bytes + (size_t)ch * 128;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int row0 = wave * 16 + j * 8;
+            const int row = row0 + prow;
+            const int c = pslot ^ ((row >> 1) & 7);
+            glds16(wb + (size_t)row * row_bytes + c * 16, smem + LDS_W + slot * 8192 + row0 * 128);
+        }
+    };
+    auto stage_a = [&](int ch, int piece, int buf) {
+        const int id = piece * 4 + wave;  // 0..31, 8 rows each
+        const int row = id * 8 + prow;    // 0..255 = board*64 + pixel slot
+        const int c = pslot ^ ((row >> 1) & 7);
+        const char* src = reinterpret_cast<const char*>(in) + ((size_t)b0 * SLOTS + row) * row_bytes + (size_t)ch * 128 + c * 16;
+        glds16(src, smem + LDS_ACT + buf * 32768 + id * 1024);
+    };
+    auto stage_dummy = [&]() {
+        glds16(reinterpret_cast<const char*>(w) + lane * 16, smem + LDS_SCRATCH + wave * 1024);
+    };
+
+    // ---- per-lane geometry ----
+    int ph[2], pw[2];
+    bool pvalid[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) {
+        const int p = pb * 32 + r;
+        ph[pb] = p / S;
+        pw[pb] = p - ph[pb] * S;
+        pvalid[pb] = p < S * S;
+    }
+    int arow[2], ax0[2];  // weight fragment rows: LDS byte offset of the row, swizzle term
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        const int row = cb * 32 + r;
+        arow[cb] = row * 128;
+        ax0[cb] = (h ^ ((row >> 1) & 7)) << 4;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    // ---- prologue: activation chunk 0, weight slabs 0 and 1 ----
+#pragma unroll
+    for (int pc = 0; pc < 8; pc++) stage_a(0, pc, 0);
+    stage_w(0, 0);
+    stage_w(1, 1);
+
+    int ch = 0, tap = 0;
+    for (int t = 0; t < T_total; t++) {
+        // Everything step t reads was issued before step t-1's loads: allow only those 3 in flight.
+        if (t == 0)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+
+        // Issue: next chunk's activation piece (taps 0..7) and the weight slab of step t+2.
+        if (tap < 8 && ch + 1 < nch)
+            stage_a(ch + 1, tap, (ch + 1) & 1);
+        else
+            stage_dummy();
+        if (t + 2 < T_total) {
+            stage_w(t + 2, (t + 2) % 3);
+        } else {
+            stage_dummy();
+            stage_dummy();
+        }
+
+        // ---- compute step t ----
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int abase = LDS_ACT + (ch & 1) * 32768 + wave * 8192;
+        const int wbase = LDS_W + (t % 3) * 8192;
+        int brow[2], bx0[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; pb++) {
+            const int hh = ph[pb] + dy, ww = pw[pb] + dx;
+            const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
+            const int q = hh * S + ww;
+            brow[pb] = ok ? abase + q * 128 : LDS_ZERO;
+            bx0[pb] = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            frag a[2], b[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++)
+                a[cb] = *reinterpret_cast<const frag*>(smem + wbase + arow[cb] + (ax0[cb] ^ (ks << 5)));
+#pragma unroll
+            for (int pb = 0; pb < 2; pb++)
+                b[pb] = *reinterpret_cast<const frag*>(smem + brow[pb] + (bx0[pb] ^ (ks << 5)));
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(a[cb], b[pb], acc[cb][pb]);
+        }
+
+        if (++tap == 9) {
+            tap = 0;
+            ch++;
+        }
+    }
+    // Dummy DMA pieces may still be in flight: they must land before this workgroup's LDS is reused.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: + bias (+ residual), ReLU, NHWC store; lane holds 4 consecutive couts per group ----
+    const size_t board = (size_t)(b0 + wave);
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int pb = 0; pb < 2; pb++) {
+            const int p = pb * 32 + r;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = cout0 + cb * 32 + g * 8 + h * 4;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
+                const size_t off = (board * SLOTS + p) * (size_t)cout + co;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
+                if (HAS_RES) {
+                    T rv[4];
+                    if (sizeof(T) == 2)
+                        *reinterpret_cast<uint64_t*>(rv) = *reinterpret_cast<const uint64_t*>(res + off);
+                    else
+                        *reinterpret_cast<f32x4*>(rv) = *reinterpret_cast<const f32x4*>(res + off);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = v[i] + (float)rv[i];
+                }
+                T ov[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float y = v[i] > 0.0f ? v[i] : 0.0f;
+                    if (!pvalid[pb]) y = 0.0f;
+                    ov[i] = (T)y;
+                }
+                if (sizeof(T) == 2)
+                    *reinterpret_cast<uint64_t*>(out + off) = *reinterpret_cast<uint64_t*>(ov);
+                else
+                    *reinterpret_cast<f32x4*>(out + off) = *reinterpret_cast<f32x4*>(ov);
+            }
+        }
+}
+
+void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
+                         uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st) {
+    const dim3 grid((bpad / BOARDS_PER_WG) * (cout / COUT_PER_WG)), block(256);
+#define CATTUS_LAUNCH_CONV(T, R)                                                                          \
+    do {                                                                                                  \
+        static bool attr_set = false;                                                                     \
+        if (!attr_set) {                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<T, R>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);             \
+            attr_set = true;                                                                              \
+        }                                                                                                 \
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<T, R>), grid, block, LDS_TOTAL, st, (const T*)in, (const T*)w, bias, \
+                           (const T*)res, (T*)out, (int)cin, (int)cout, (int)S);                          \
+    } while (0)
+    if (act == Act::BF16) {
+        if (res) CATTUS_LAUNCH_CONV(__bf16, true);
+        else CATTUS_LAUNCH_CONV(__bf16, false);
+    } else {
+        if (res) CATTUS_LAUNCH_CONV(float, true);
+        else CATTUS_LAUNCH_CONV(float, false);
+    }
+#undef CATTUS_LAUNCH_CONV
+}
+
+// ------------------------------------------------------------------------------------------
+// K1g: generic direct conv, f32 NCHW, one thread per output element, canonical chain order
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv3x3_generic_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ res, float* __restrict__ out,
+                                                              uint32_t total, int cin, int cout, int S) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int hw = S * S;
+    const int p = e % hw, co = (e / hw) % cout, b = e / (hw * cout);
+    const int ph = p / S, pw = p - ph * S;
+    const float* xb = in + (size_t)b * cin * hw;
+    float acc = 0.0f;
+    const int nch = (cin + 31) / 32;
+    for (int ch = 0; ch < nch; ch++)
+        for (int tap = 0; tap < 9; tap++) {
+            const int hh = ph + tap / 3 - 1, ww = pw + tap % 3 - 1;
+            const bool ok = (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
+            const int q = hh * S + ww;
+            const float* wr = w + ((size_t)tap * cout + co) * cin;
+            for (int kk = 0; kk < 32; kk++) {
+                const int k = ch * 32 + (kk & ~7) + ((kk & 1) << 2) + ((kk & 7) >> 1);  // 0,4,1,5,2,6,3,7
+                if (k >= cin) continue;
+                const float x = ok ? xb[(size_t)k * hw + q] : 0.0f;
+                acc = __builtin_fmaf(wr[k], x, acc);
+            }
+        }
+    float y = acc + bias[co];
+    if (res) y = y + res[e];
+    out[e] = y > 0.0f ? y : 0.0f;
+}
+
+void launch_conv3x3_generic(const float* in, const float* w, const float* bias, const float* res, float* out,
+                            uint32_t b, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st) {
+    const uint32_t total = b * cout * S * S;
+    if (!total) return;
+    hipLaunchKernelGGL(conv3x3_generic_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, w, bias, res, out,
+                       total, (int)cin, (int)cout, (int)S);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3-K5: heads
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) head_conv1x1_kernel(const T* __restrict__ x, uint32_t sb, uint32_t sk, uint32_t sp,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           uint32_t total, uint32_t F, uint32_t ocn, uint32_t hw,
+                                                           float* __restrict__ hv) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const uint32_t p = e % hw, oc = (e / hw) % ocn, b = e / (hw * ocn);
+    const T* xp = x + (size_t)b * sb + (size_t)p * sp;
+    const float* wr = w + (size_t)oc * F;
+    float acc = 0.0f;
+    for (uint32_t k = 0; k < F; k++) acc = __builtin_fmaf(wr[k], (float)xp[(size_t)k * sk], acc);
+    const float y = acc + bias[oc];
+    hv[e] = y > 0.0f ? y : 0.0f;
+}
+
+void launch_head_conv1x1(TowerView x, const float* w, const float* bias, uint32_t b, uint32_t F, uint32_t ocn,
+                         uint32_t hw, float* hv, hipStream_t st) {
+    const uint32_t total = b * ocn * hw;
+    if (!total) return;
+    const dim3 grid((total + 255) / 256), block(256);
+    if (x.act == Act::BF16)
+        hipLaunchKernelGGL(head_conv1x1_kernel<__bf16>, grid, block, 0, st, (const __bf16*)x.x, x.sb, x.sk, x.sp, w, bias,
+                           total, F, ocn, hw, hv);
+    else
+        hipLaunchKernelGGL(head_conv1x1_kernel<float>, grid, block, 0, st, (const float*)x.x, x.sb, x.sk, x.sp, w, bias,
+                           total, F, ocn, hw, hv);
+}
+
+__global__ void __launch_bounds__(128) value_fc1_kernel(const float* __restrict__ hv, uint32_t hv_stride,
+                                                        const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                        uint32_t K, float* __restrict__ h1) {
+    const uint32_t b = blockIdx.x, j = threadIdx.x;
+    const float* x = hv + (size_t)b * hv_stride;
+    float acc = 0.0f;
+    for (uint32_t k = 0; k < K; k++) acc = __builtin_fmaf(w1t[(size_t)k * 128 + j], x[k], acc);
+    const float y = acc + b1[j];
+    h1[(size_t)b * 128 + j] = y > 0.0f ? y : 0.0f;
+}
+
+void launch_value_fc1(const float* hv, uint32_t hv_stride, const float* w1t, const float* b1, uint32_t b, uint32_t K,
+                      float* h1, hipStream_t st) {
+    if (!b) return;
+    hipLaunchKernelGGL(value_fc1_kernel, dim3(b), dim3(128), 0, st, hv, hv_stride, w1t, b1, K, h1);
+}
+
+// tanh from + - * / fmaf and exponent-bit edits only, so the CPU oracle reproduces it bit for bit.
+__device__ __forceinline__ float exp_pos(float x) {
+    const float log2e = 1.44269504088896341f;
+    const float ln2_hi = 0.693145751953125f;
+    const float ln2_lo = 1.42860682030941723e-06f;
+    const float nf = __builtin_rintf(x * log2e);
+    float rr = __builtin_fmaf(nf, -ln2_hi, x);
+    rr = __builtin_fmaf(nf, -ln2_lo, rr);
+    float p = 1.0f / 720.0f;
+    p = __builtin_fmaf(p, rr, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, rr, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, rr, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, rr, 0.5f);
+    p = __builtin_fmaf(p, rr, 1.0f);
+    p = __builtin_fmaf(p, rr, 1.0f);
+    return __uint_as_float(__float_as_uint(p) + (((uint32_t)(int32_t)nf) << 23));
+}
+
+__device__ __forceinline__ float tanh_exact(float x) {
+    const float ax = __builtin_fabsf(x);
+    float t;
+    if (!(ax == ax)) return x;
+    if (ax < 0.5f) {
+        const float s = ax * ax;
+        float p = 21844.0f / 6081075.0f;
+        p = __builtin_fmaf(p, s, -1382.0f / 155925.0f);
+        p = __builtin_fmaf(p, s, 62.0f / 2835.0f);
+        p = __builtin_fmaf(p, s, -17.0f / 315.0f);
+        p = __builtin_fmaf(p, s, 2.0f / 15.0f);
+        p = __builtin_fmaf(p, s, -1.0f / 3.0f);
+        t = __builtin_fmaf(ax * s, p, ax);
+    } else if (ax < 10.0f) {
+        const float e = exp_pos(2.0f * ax);
+        t = 1.0f - 2.0f / (e + 1.0f);
+    } else {
+        t = 1.0f;
+    }
+    return x < 0.0f ? -t : t;
+}
+
+__global__ void __launch_bounds__(256) value_fc2_tanh_kernel(const float* __restrict__ h1, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, uint32_t nb,
+                                                             float* __restrict__ value) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+    const float* x = h1 + (size_t)b * 128;
+    float acc = 0.0f;
+    for (int j = 0; j < 128; j++) acc = __builtin_fmaf(w2[j], x[j], acc);
+    value[b] = tanh_exact(acc + b2[0]);
+}
+
+void launch_value_fc2_tanh(const float* h1, const float* w2, const float* b2, uint32_t b, float* value, hipStream_t st) {
+    if (!b) return;
+    hipLaunchKernelGGL(value_fc2_tanh_kernel, dim3((b + 255) / 256), dim3(256), 0, st, h1, w2, b2, b, value);
+}
+
+// Block = 256 logits x 8 leaves; the 8 input rows are staged in LDS, every weight is loaded once
+// (coalesced along m) and used for 8 fmaf.
+constexpr int PFC_ROWS = 8;
+__global__ void __launch_bounds__(256) policy_fc_kernel(const float* __restrict__ hv, uint32_t hv_stride, uint32_t off,
+                                                        const float* __restrict__ wpt, const float* __restrict__ bp,
+                                                        uint32_t nb, uint32_t K, uint32_t M, float* __restrict__ policy) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);  // [PFC_ROWS][K]
+    const uint32_t b0 = blockIdx.y * PFC_ROWS;
+    for (uint32_t i = threadIdx.x; i < PFC_ROWS * K; i += 256) {
+        const uint32_t rr = i / K, k = i - rr * K;
+        xs[i] = (b0 + rr < nb) ? hv[(size_t)(b0 + rr) * hv_stride + off + k] : 0.0f;
+    }
+    __syncthreads();
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float acc[PFC_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < PFC_ROWS; rr++) acc[rr] = 0.0f;
+    for (uint32_t k = 0; k < K; k++) {
+        const float wv = wpt[(size_t)k * M + m];
+#pragma unroll
+        for (int rr = 0; rr < PFC_ROWS; rr++) acc[rr] = __builtin_fmaf(wv, xs[rr * K + k], acc[rr]);
+    }
+    const float bias = bp[m];
+#pragma unroll
+    for (int rr = 0; rr < PFC_ROWS; rr++) {
+        if (b0 + rr >= nb) break;
+        float y = acc[rr] + bias;
+        // non-finite logits -> f32::MIN (reference: engine/src/net/mod.rs:56-61)
+        if (!(__builtin_fabsf(y) <= 3.40282347e+38f)) y = -3.40282347e+38f;
+        policy[(size_t)(b0 + rr) * M + m] = y;
+    }
+}
+
+void launch_policy_fc(const float* hv, uint32_t hv_stride, uint32_t off, const float* wpt, const float* bp, uint32_t b,
+                      uint32_t K, uint32_t M, float* policy, hipStream_t st) {
+    if (!b) return;
+    const dim3 grid((M + 255) / 256, (b + PFC_ROWS - 1) / PFC_ROWS), block(256);
+    hipLaunchKernelGGL(policy_fc_kernel, grid, block, PFC_ROWS * K * sizeof(float), st, hv, hv_stride, off, wpt, bp, b, K,
+                       M, policy);
+}
+
+}  // namespace cattus

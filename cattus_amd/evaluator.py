@@ -1,0 +1,234 @@
+"""ctypes binding of ``libcattus_hip.so`` (include/cattus_hip.h).
+
+``HipEvaluator`` plays the role of the reference's ``NNetwork`` + ``Model`` pair
+(engine/src/net/mod.rs:14-72, engine/src/net/model.rs:57-218): ``run_net`` takes the leaves of
+one batch and returns ``[(logits, value), ...]``; ``planes_to_tensor`` is the stand-alone
+tensor packer (engine/src/net/mod.rs:121-156).  There is no CPU implementation behind these
+calls: if the shared library is missing or no HIP device is usable they raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from .weights import NetDesc, parse_header
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libcattus_hip.so"
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+_DTYPES = {"f32": DTYPE_F32, "bf16": DTYPE_BF16}
+
+# every symbol include/cattus_hip.h declares
+ABI_SYMBOLS = [
+    "cattus_hip_create",
+    "cattus_hip_destroy",
+    "cattus_hip_desc",
+    "cattus_hip_eval",
+    "cattus_hip_eval_device",
+    "cattus_hip_submit",
+    "cattus_hip_wait",
+    "cattus_hip_flush",
+    "cattus_hip_stats",
+    "cattus_hip_time_tower",
+    "cattus_hip_planes_to_tensor",
+    "cattus_hip_planes_to_tensor_device",
+    "cattus_hip_last_error",
+    "cattus_hip_version",
+]
+
+
+class CattusHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"cattus_hip status {status}: {message}")
+        self.status = status
+
+
+class EvalConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("max_batch", C.c_uint32),
+        ("plane_words", C.c_uint32),
+        ("dtype", C.c_uint32),
+        ("flush_us", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("batches", C.c_uint64),
+        ("positions", C.c_uint64),
+        ("full_batches", C.c_uint64),
+        ("run_seconds_ema", C.c_double),
+        ("run_seconds_total", C.c_double),
+    ]
+
+
+class NetDescC(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("planes", "board", "moves", "blocks", "filters", "vhc", "phc", "fc_hidden")]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libcattus_hip.so from the package directory; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -m cattus_amd.build` "
+            "(there is no CPU fallback for the leaf evaluator)"
+        )
+    L = C.CDLL(str(LIB_PATH))
+    u64p, f32p = C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+    vp = C.c_void_p
+    L.cattus_hip_create.argtypes = [vp, C.c_size_t, C.POINTER(EvalConfig), C.POINTER(vp)]
+    L.cattus_hip_destroy.argtypes = [vp]
+    L.cattus_hip_destroy.restype = None
+    L.cattus_hip_desc.argtypes = [vp, C.POINTER(NetDescC)]
+    L.cattus_hip_eval.argtypes = [vp, u64p, C.c_uint32, f32p, f32p]
+    L.cattus_hip_eval_device.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+    L.cattus_hip_submit.argtypes = [vp, u64p, C.POINTER(C.c_uint64)]
+    L.cattus_hip_wait.argtypes = [vp, C.c_uint64, f32p, f32p]
+    L.cattus_hip_flush.argtypes = [vp]
+    L.cattus_hip_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.cattus_hip_time_tower.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.cattus_hip_planes_to_tensor.argtypes = [C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
+    L.cattus_hip_planes_to_tensor_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.cattus_hip_last_error.restype = C.c_char_p
+    L.cattus_hip_version.restype = C.c_char_p
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("cattus_hip_last_error", "cattus_hip_version"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise CattusHipError(rc, load_library().cattus_hip_last_error().decode(errors="replace"))
+
+
+def _u64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def planes_to_tensor(planes: np.ndarray, board: int, batch_size: int, device: int = 0) -> np.ndarray:
+    """HIP drop-in for ``planes_to_tensor`` (engine/src/net/mod.rs:121-156).
+
+    planes: uint64 ``[n, C, plane_words]`` -> float32 ``[batch_size, C, S, S]``, rows ``n..`` zero.
+    """
+    planes = np.ascontiguousarray(planes, dtype=np.uint64)
+    n, c, w64 = planes.shape
+    out = np.empty((batch_size, c, board, board), dtype=np.float32)
+    _check(load_library().cattus_hip_planes_to_tensor(device, _u64(planes), n, c, w64, board, batch_size, _f32(out)))
+    return out
+
+
+class HipEvaluator:
+    """One network resident on one MI355X.
+
+    Mirrors ``NNetwork::new(model_path, inference_cfg, batch_size, cache)`` (net/mod.rs:24-39) with
+    the weight blob in place of the model path and ``{"engine": "hip", "device", "dtype"}`` in place
+    of ``InferenceConfig``.
+    """
+
+    def __init__(
+        self,
+        blob: bytes,
+        batch_size: int,
+        plane_words: int,
+        dtype: str = "bf16",
+        device: int = 0,
+        flush_us: int = 200,
+    ):
+        self.desc: NetDesc = parse_header(blob)
+        self.batch_size = int(batch_size)
+        self.plane_words = int(plane_words)
+        self.dtype = dtype
+        self.device = device
+        self._lib = load_library()
+        cfg = EvalConfig(C.sizeof(EvalConfig), device, self.batch_size, self.plane_words, _DTYPES[dtype], flush_us)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(blob, len(blob))
+        _check(self._lib.cattus_hip_create(buf, len(blob), C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cattus_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- evaluation -------------------------------------------------------------------------
+    def _planes(self, planes) -> np.ndarray:
+        planes = np.ascontiguousarray(planes, dtype=np.uint64)
+        if planes.ndim != 3 or planes.shape[1:] != (self.desc.planes, self.plane_words):
+            raise ValueError(f"planes shape {planes.shape} != [n, {self.desc.planes}, {self.plane_words}]")
+        return planes
+
+    def eval(self, planes) -> tuple[np.ndarray, np.ndarray]:
+        """planes uint64 ``[n, C, plane_words]`` -> (logits ``[n, M]``, values ``[n]``)."""
+        planes = self._planes(planes)
+        n = planes.shape[0]
+        policy = np.empty((n, self.desc.moves), dtype=np.float32)
+        value = np.empty((n,), dtype=np.float32)
+        _check(self._lib.cattus_hip_eval(self._h, _u64(planes), n, _f32(policy), _f32(value)))
+        return policy, value
+
+    def run_net(self, planes) -> list[tuple[np.ndarray, float]]:
+        """``NNetwork::run_net`` (net/mod.rs:41-72): one ``(logits, value)`` pair per leaf."""
+        policy, value = self.eval(planes)
+        return [(policy[i], float(value[i])) for i in range(len(value))]
+
+    def eval_device(self, d_planes: int, n: int, d_policy: int, d_value: int, stream: int = 0):
+        """Asynchronous evaluation on raw device pointers (all buffers resident in HBM)."""
+        _check(self._lib.cattus_hip_eval_device(self._h, d_planes, n, d_policy, d_value, stream))
+
+    # -- leaf server (Batcher::apply replacement, util/batch.rs:49-177) ---------------------
+    def submit(self, planes_one) -> int:
+        p = np.ascontiguousarray(planes_one, dtype=np.uint64).reshape(self.desc.planes, self.plane_words)
+        t = C.c_uint64()
+        _check(self._lib.cattus_hip_submit(self._h, _u64(p), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int) -> tuple[np.ndarray, float]:
+        policy = np.empty((self.desc.moves,), dtype=np.float32)
+        value = C.c_float()
+        _check(self._lib.cattus_hip_wait(self._h, ticket, _f32(policy), C.byref(value)))
+        return policy, value.value
+
+    def flush(self):
+        _check(self._lib.cattus_hip_flush(self._h))
+
+    # -- introspection ----------------------------------------------------------------------
+    def stats(self) -> dict:
+        s = Stats()
+        _check(self._lib.cattus_hip_stats(self._h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in Stats._fields_}
+
+    def time_tower(self, n: int, reps: int) -> tuple[float, int]:
+        """(average device microseconds of one tower conv launch, launches per forward)."""
+        us, launches = C.c_float(), C.c_uint32()
+        _check(self._lib.cattus_hip_time_tower(self._h, n, reps, C.byref(us), C.byref(launches)))
+        return us.value, launches.value

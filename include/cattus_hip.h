@@ -1,0 +1,113 @@
+/*
+ * cattus_hip.h -- C ABI of the MI355X leaf evaluator for Cattus self-play.
+ *
+ * This library is the drop-in for the reference's leaf-evaluation seam: the closure body of
+ * Batcher::apply inside NNetwork::evaluate_impl (engine/src/net/mod.rs:94-98), i.e.
+ *     planes_to_tensor (engine/src/net/mod.rs:121-156)
+ *  -> NNetwork::run_net (engine/src/net/mod.rs:41-72)
+ *  -> Model::run        (engine/src/net/model.rs:146-218)
+ * Input per leaf: the position's bitboard planes (position_to_planes,
+ * engine/src/chess/net/mod.rs:19-60, hex/net.rs:14-24, ttt/net.rs:14-24) for the position
+ * already flipped so Player1 is to move (net/mod.rs:79).  Output per leaf: the M raw policy
+ * logits with non-finite values replaced by f32::MIN (net/mod.rs:56-61) and the tanh value.
+ * Everything above the seam (flip, cache, legal-move softmax, MCTS) is unchanged.
+ *
+ * Conventions: every entry point returns 0 (CATTUS_OK) or a negative cattus_status; it never
+ * throws, aborts or keeps a caller pointer.  cattus_hip_last_error() returns a thread-local
+ * message for the last failing call on the calling thread.  All entry points are thread-safe.
+ */
+#ifndef CATTUS_HIP_H
+#define CATTUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cattus_eval cattus_eval;
+
+typedef enum cattus_status {
+    CATTUS_OK = 0,
+    CATTUS_E_INVALID = -1,     /* bad argument (the reference would panic: model.rs:100-125) */
+    CATTUS_E_UNSUPPORTED = -2, /* shape/dtype combination this build has no kernel for */
+    CATTUS_E_DEVICE = -3,      /* HIP runtime error; message in last_error */
+    CATTUS_E_NOMEM = -4,
+    CATTUS_E_STATE = -5,       /* unknown / already-collected ticket, evaluator shut down */
+} cattus_status;
+
+typedef enum cattus_dtype {
+    CATTUS_DTYPE_F32 = 0,  /* exact f32 MFMA, bit-identical to the CPU oracle's summation order */
+    CATTUS_DTYPE_BF16 = 1, /* bf16 operands / f32 accumulate MFMA tower (throughput mode) */
+} cattus_dtype;
+
+/* Replaces the reference's InferenceConfig + batch_size (engine/src/net/model.rs:17-25,
+ * training/self-play/src/self_play_cmd.rs:41-44). */
+typedef struct cattus_eval_config {
+    uint32_t struct_size; /* sizeof(cattus_eval_config) */
+    int32_t device;       /* HIP device ordinal */
+    uint32_t max_batch;   /* model.batch_size: largest n accepted by eval / batch the server fills */
+    uint32_t plane_words; /* u64 words per bitboard plane: chess 1, ttt 1, hex 2 (u128 as lo,hi) */
+    uint32_t dtype;       /* cattus_dtype */
+    uint32_t flush_us;    /* partial-batch deadline of the leaf server (reference: 20 ms, net/mod.rs:96) */
+} cattus_eval_config;
+
+typedef struct cattus_stats {
+    uint64_t batches;       /* == reference metric model.activation_count (net/mod.rs:68) */
+    uint64_t positions;     /* real (non-padded) leaves evaluated */
+    uint64_t full_batches;  /* batches that ran with n == max_batch */
+    double run_seconds_ema; /* == reference metric model.run_duration (EMA 0.99, util/metric.rs:16-19) */
+    double run_seconds_total;
+} cattus_stats;
+
+/* Network shape as stored in the weight blob header (cattus_amd/weights.py). */
+typedef struct cattus_net_desc {
+    uint32_t planes, board, moves, blocks, filters, vhc, phc, fc_hidden;
+} cattus_net_desc;
+
+/* Model::new (model.rs:61): parse the weight blob (copied), fold BatchNorm, upload. */
+int cattus_hip_create(const void* weights, size_t nbytes, const cattus_eval_config* cfg, cattus_eval** out);
+void cattus_hip_destroy(cattus_eval* e);
+int cattus_hip_desc(const cattus_eval* e, cattus_net_desc* out);
+
+/* planes_to_tensor + run_net for n leaves, blocking (1 <= n <= max_batch, net/mod.rs:122-127).
+ * planes: [n][planes][plane_words] u64 host memory; policy: [n][moves]; value: [n]. */
+int cattus_hip_eval(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy, float* value);
+
+/* Same with every buffer already resident in device memory (HBM) and asynchronous on `stream`
+ * (a hipStream_t; NULL = the evaluator's own stream).  Used by bench.py so that the timed
+ * region excludes PCIe. */
+int cattus_hip_eval_device(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float* d_policy,
+                           float* d_value, void* stream);
+
+/* Leaf-batching server, the replacement of Batcher::apply (engine/src/util/batch.rs:49-177):
+ * submit copies one leaf's planes and returns a ticket; wait blocks until that leaf's batch ran
+ * and copies its logits/value out.  A batch runs when max_batch leaves are queued, when the oldest
+ * queued leaf is flush_us old, or on cattus_hip_flush. */
+int cattus_hip_submit(cattus_eval* e, const uint64_t* planes_one, uint64_t* ticket);
+int cattus_hip_wait(cattus_eval* e, uint64_t ticket, float* policy, float* value);
+int cattus_hip_flush(cattus_eval* e);
+
+int cattus_hip_stats(cattus_eval* e, cattus_stats* out);
+
+/* Average device time in microseconds of one 3x3-conv tower launch over `reps` forwards of n
+ * leaves, measured with HIP events recorded around each launch on the evaluator's stream.
+ * also returns the number of such launches per forward. */
+int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, float* avg_launch_us, uint32_t* launches);
+
+/* Stand-alone planes_to_tensor (engine/src/net/mod.rs:121-156): host planes [n][C][plane_words]
+ * -> host f32 tensor [batch][C][S][S], rows n..batch zero. */
+int cattus_hip_planes_to_tensor(int device, const uint64_t* planes, uint32_t n, uint32_t C, uint32_t plane_words,
+                                uint32_t S, uint32_t batch, float* out);
+/* Device-resident variant, asynchronous on `stream`. */
+int cattus_hip_planes_to_tensor_device(const uint64_t* d_planes, uint32_t n, uint32_t C, uint32_t plane_words,
+                                       uint32_t S, uint32_t batch, float* d_out, void* stream);
+
+const char* cattus_hip_last_error(void);
+const char* cattus_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATTUS_HIP_H */

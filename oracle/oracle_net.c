@@ -31,6 +31,7 @@
  *   - tanh: oracle_tanhf below (only + - * / fmaf and exponent bit edits).
  * Build with -ffp-contract=off so no other fusion happens.
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -261,54 +262,88 @@ fail:
 static const int KPERM[8] = {0, 4, 1, 5, 2, 6, 3, 7};
 
 /* One 3x3 'same' conv for one position in the canonical order.
- * in : [cin][S*S], out: [cout][S*S]; res (optional): [cout][S*S]. */
-static inline __attribute__((always_inline)) void conv3x3_impl(const conv3_layer *L, const float *in,
-                                                               const float *res, float *out,
-                                                               const uint32_t S) {
-    const uint32_t hw = S * S, P = S + 2, cin = L->cin, cout = L->cout;
-    float *xpad = (float *)calloc((size_t)cin * P * P, sizeof(float));
-    for (uint32_t c = 0; c < cin; c++)
-        for (uint32_t h = 0; h < S; h++)
-            for (uint32_t w = 0; w < S; w++) xpad[(size_t)c * P * P + (h + 1) * P + (w + 1)] = in[c * hw + h * S + w];
-    const uint32_t nchunks = (cin + 31) / 32;
-    for (uint32_t co = 0; co < cout; co++) {
-        float acc[MAX_HW];
-        for (uint32_t i = 0; i < hw; i++) acc[i] = 0.0f;
-        for (uint32_t ch = 0; ch < nchunks; ch++)
-            for (uint32_t tap = 0; tap < 9; tap++) {
-                const uint32_t ty = tap / 3, tx = tap % 3; /* dy = ty-1, dx = tx-1 */
-                const float *wrow = L->w + ((size_t)tap * cout + co) * cin;
-                for (uint32_t kk = 0; kk < 32; kk++) {
-                    const uint32_t k = ch * 32 + (kk & ~7u) + (uint32_t)KPERM[kk & 7];
-                    if (k >= cin) continue;
-                    const float wv = wrow[k];
-                    const float *xp = xpad + (size_t)k * P * P + ty * P + tx;
-                    for (uint32_t h = 0; h < S; h++)
-                        for (uint32_t w = 0; w < S; w++)
-                            acc[h * S + w] = __builtin_fmaf(wv, xp[h * P + w], acc[h * S + w]);
-                }
-            }
-        const float b = L->b[co];
-        for (uint32_t i = 0; i < hw; i++) {
-            float y = acc[i] + b;
-            if (res) y = y + res[co * hw + i];
-            out[co * hw + i] = y > 0.0f ? y : 0.0f;
-        }
-    }
+ * in : [cin][S*S], out: [cout][S*S]; res (optional): [cout][S*S].
+ * The board is held zero-padded with row pitch P = S+2; outputs are accumulated over the padded
+ * flat index i = h*P + w (columns w >= S are scratch), so each (cout, k, tap) update is one
+ * contiguous fmaf sweep (SWEEP below: 16-, 8- or 1-wide).  Every real output still sees exactly
+ * the canonical chain: one fmaf per (chunk, tap, k) in that order, zero taps included; a vector
+ * fma lane rounds exactly like fmaf. */
+#define ACC_MAX (MAX_S * (MAX_S + 2) + 16)
+#define CONV3X3_BODY(SWEEP)                                                                              \
+    const uint32_t hw = S * S, P = S + 2, cin = L->cin, cout = L->cout;                                   \
+    const uint32_t span = (S * P + 15) & ~15u;                                                            \
+    const uint32_t plane = P * P + P + 32; /* slack: the last tap's sweep stays in bounds */              \
+    float *xpad = (float *)calloc((size_t)cin * plane, sizeof(float));                                    \
+    for (uint32_t c = 0; c < cin; c++)                                                                    \
+        for (uint32_t h = 0; h < S; h++)                                                                  \
+            for (uint32_t w = 0; w < S; w++)                                                              \
+                xpad[(size_t)c * plane + (h + 1) * P + (w + 1)] = in[c * hw + h * S + w];                 \
+    const uint32_t nchunks = (cin + 31) / 32;                                                             \
+    for (uint32_t co = 0; co < cout; co++) {                                                              \
+        float acc[ACC_MAX] __attribute__((aligned(64)));                                                  \
+        for (uint32_t i = 0; i < span; i++) acc[i] = 0.0f;                                                \
+        for (uint32_t ch = 0; ch < nchunks; ch++)                                                         \
+            for (uint32_t tap = 0; tap < 9; tap++) {                                                      \
+                const uint32_t ty = tap / 3, tx = tap % 3; /* dy = ty-1, dx = tx-1 */                     \
+                const float *wrow = L->w + ((size_t)tap * cout + co) * cin;                               \
+                for (uint32_t kk = 0; kk < 32; kk++) {                                                    \
+                    const uint32_t k = ch * 32 + (kk & ~7u) + (uint32_t)KPERM[kk & 7];                    \
+                    if (k >= cin) continue;                                                               \
+                    const float wv = wrow[k];                                                             \
+                    const float *xp = xpad + (size_t)k * plane + ty * P + tx;                             \
+                    SWEEP(acc, xp, wv, span);                                                             \
+                }                                                                                         \
+            }                                                                                             \
+        const float b = L->b[co];                                                                         \
+        for (uint32_t h = 0; h < S; h++)                                                                  \
+            for (uint32_t w = 0; w < S; w++) {                                                            \
+                const uint32_t i = h * S + w;                                                             \
+                float y = acc[h * P + w] + b;                                                             \
+                if (res) y = y + res[co * hw + i];                                                        \
+                out[co * hw + i] = y > 0.0f ? y : 0.0f;                                                   \
+            }                                                                                             \
+    }                                                                                                     \
     free(xpad);
+
+#define SWEEP_SCALAR(acc, xp, wv, span) \
+    for (uint32_t i = 0; i < (span); i++) (acc)[i] = __builtin_fmaf((wv), (xp)[i], (acc)[i])
+#define SWEEP_AVX2(acc, xp, wv, span)                                                                    \
+    do {                                                                                                  \
+        const __m256 wv8 = _mm256_set1_ps(wv);                                                            \
+        for (uint32_t i = 0; i < (span); i += 8)                                                          \
+            _mm256_store_ps((acc) + i, _mm256_fmadd_ps(wv8, _mm256_loadu_ps((xp) + i), _mm256_load_ps((acc) + i))); \
+    } while (0)
+#define SWEEP_AVX512(acc, xp, wv, span)                                                                  \
+    do {                                                                                                  \
+        const __m512 wv16 = _mm512_set1_ps(wv);                                                           \
+        for (uint32_t i = 0; i < (span); i += 16)                                                         \
+            _mm512_store_ps((acc) + i, _mm512_fmadd_ps(wv16, _mm512_loadu_ps((xp) + i), _mm512_load_ps((acc) + i))); \
+    } while (0)
+
+static void conv3x3_scalar(const conv3_layer *L, const float *in, const float *res, float *out, uint32_t S) {
+    CONV3X3_BODY(SWEEP_SCALAR)
+}
+__attribute__((target("avx2,fma"))) static void conv3x3_avx2(const conv3_layer *L, const float *in,
+                                                             const float *res, float *out, uint32_t S) {
+    CONV3X3_BODY(SWEEP_AVX2)
+}
+__attribute__((target("avx512f"))) static void conv3x3_avx512(const conv3_layer *L, const float *in,
+                                                              const float *res, float *out, uint32_t S) {
+    CONV3X3_BODY(SWEEP_AVX512)
 }
 
-HOT static void conv3x3(const conv3_layer *L, const float *in, const float *res, float *out, uint32_t S) {
-    switch (S) {
-        case 3: conv3x3_impl(L, in, res, out, 3); break;
-        case 4: conv3x3_impl(L, in, res, out, 4); break;
-        case 5: conv3x3_impl(L, in, res, out, 5); break;
-        case 7: conv3x3_impl(L, in, res, out, 7); break;
-        case 8: conv3x3_impl(L, in, res, out, 8); break;
-        case 9: conv3x3_impl(L, in, res, out, 9); break;
-        case 11: conv3x3_impl(L, in, res, out, 11); break;
-        default: conv3x3_impl(L, in, res, out, S); break;
+static void conv3x3(const conv3_layer *L, const float *in, const float *res, float *out, uint32_t S) {
+    static int isa = -1; /* 0 scalar, 1 avx2+fma, 2 avx512f; all three give identical bits */
+    if (isa < 0) {
+        const char *force = getenv("ORACLE_ISA");
+        __builtin_cpu_init();
+        int v = __builtin_cpu_supports("avx512f") ? 2 : (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? 1 : 0;
+        if (force) v = atoi(force) < v ? atoi(force) : v;
+        isa = v;
     }
+    if (isa == 2) conv3x3_avx512(L, in, res, out, S);
+    else if (isa == 1) conv3x3_avx2(L, in, res, out, S);
+    else conv3x3_scalar(L, in, res, out, S);
 }
 
 /* 1x1 conv + folded BN + ReLU: out[oc][p] = relu(chain_k(w[oc][k]*in[k][p]) + b[oc]) */
