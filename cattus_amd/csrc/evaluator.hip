@@ -543,8 +543,9 @@ CATTUS_API int cattus_hip_submit(cattus_eval* e, const uint64_t* planes_one, uin
     const size_t words = (size_t)e->d.planes * e->cfg.plane_words;
     std::unique_lock<std::mutex> lk(e->srv_mu);
     if (e->stop) return fail(CATTUS_E_STATE, "evaluator is shutting down");
-    ServerBatch* cur = e->batches.back().get();
-    if (cur->sealed) cur = new_batch(e);
+    // the deque can be empty: a deadline-sealed batch may already have been collected and erased
+    ServerBatch* cur = e->batches.empty() ? nullptr : e->batches.back().get();
+    if (!cur || cur->sealed) cur = new_batch(e);
     const uint32_t slot = cur->count++;
     if (slot == 0) cur->t0 = std::chrono::steady_clock::now();
     memcpy(cur->planes.data() + slot * words, planes_one, words * 8);
