@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -481,6 +482,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
         return fail(CATTUS_E_DEVICE, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(herr));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(CATTUS_E_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
+    if (const char* impl = getenv("CATTUS_CONV_IMPL")) set_conv_impl(atoi(impl) == 1 ? 1 : 2);
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
     if (!e) return fail(CATTUS_E_NOMEM, "out of memory");

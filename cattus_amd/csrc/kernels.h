@@ -30,6 +30,9 @@ void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st);
 
+// Selects the tower kernel variant (1 or 2); for A/B measurements only.
+void set_conv_impl(int v);
+
 // Generic f32 NCHW direct conv for shapes the MFMA kernel does not cover (any S <= 11, any C).
 // in [b][cin][hw], w [9][cout][cin], out [b][cout][hw]; same summation order as the MFMA f32 kernel.
 void launch_conv3x3_generic(const float* in, const float* w, const float* bias, const float* res, float* out,

@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(256, 1)
     const int b0 = (logical / ncb) * BOARDS_PER_WG;
 
     if (tid < 8) reinterpret_cast<f32x4*>(smem + LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
 
     const int nch = cin / KC;
     const int T_total = nch * 9;
@@ -334,9 +335,258 @@ __global__ void __launch_bounds__(256, 1)
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// K1 v2: same tiling and arithmetic, specialised wave roles
+// ------------------------------------------------------------------------------------------
+//
+// 8 waves per workgroup: waves 0-3 are MFMA consumers (one board each, as above), waves 4-7 are
+// loaders that do nothing but LDS-DMA.  One barrier per (chunk, kernel row): a step covers the
+// three taps dx = -1,0,+1 of one dy, i.e. 48 MFMAs (bf16) per consumer wave between barriers, and
+// a 24 KiB weight slab [3 taps][64 cout][128 B].  Loaders run two steps ahead (3-slab ring) and
+// fetch the next activation chunk during the first two steps of the current one.  Consumers issue
+// no global memory instruction and almost no address arithmetic inside the loop.
+//
+// The fmaf-chain order per output element is unchanged: chunk -> tap 0..8 -> k (0,4,1,5,2,6,3,7).
+constexpr int V2_SLAB = 3 * 8192;
+constexpr int V2_LDS_W = LDS_ACT + 2 * 32768;
+constexpr int V2_LDS_TOTAL = V2_LDS_W + 3 * V2_SLAB;  // 139392 B
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T, bool HAS_RES>
+__global__ void __launch_bounds__(512, 2)
+    conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S) {
+    constexpr int KC = 128 / (int)sizeof(T);
+    typedef typename Mfma<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const bool is_loader = wave >= 4;
+
+    const int nblk = gridDim.x, ncb = cout / COUT_PER_WG;
+    int logical = blockIdx.x;
+    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int cout0 = (logical % ncb) * COUT_PER_WG;
+    const int b0 = (logical / ncb) * BOARDS_PER_WG;
+
+    if (tid < 8) reinterpret_cast<f32x4*>(smem + LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
+
+    const int nch = cin / KC;
+    const int T_total = nch * 3;
+    const uint32_t row_bytes = (uint32_t)cin * sizeof(T);
+
+    if (is_loader) {
+        // ================================ loader waves ================================
+        const int lw = wave - 4;
+        const int prow = lane >> 3, pslot = lane & 7;
+        uint32_t off_w[6], off_a[2][4];
+        int dst_w[6], dst_a[2][4];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int pid = lw * 6 + i;                 // 0..23: tap_i = pid/8, 8 rows each
+            const int tap_i = pid >> 3, row = (pid & 7) * 8 + prow;
+            const int c = pslot ^ ((row >> 1) & 7);
+            off_w[i] = ((uint32_t)(tap_i * cout + row)) * row_bytes + c * 16;
+            dst_w[i] = pid * 1024;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int id = g * 16 + lw * 4 + i;     // 0..31, 8 rows each of [4 boards][64 px]
+                const int row = id * 8 + prow;
+                const int c = pslot ^ ((row >> 1) & 7);
+                off_a[g][i] = (uint32_t)row * row_bytes + c * 16;
+                dst_a[g][i] = id * 1024;
+            }
+        const char* wbase0 = reinterpret_cast<const char*>(w) + (size_t)cout0 * row_bytes;
+        const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)b0 * SLOTS * row_bytes;
+        auto issue_w = [&](int t) {  // weight slab of step t -> ring slot t % 3
+            const int ch = t / 3, g = t - ch * 3;
+            const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)ch * 128;
+            char* dst = smem + V2_LDS_W + (t % 3) * V2_SLAB;
+#pragma unroll
+            for (int i = 0; i < 6; i++) glds16(src + off_w[i], dst + dst_w[i]);
+        };
+        auto issue_a = [&](int ch, int g) {  // half g of activation chunk ch -> buffer ch & 1
+            const char* src = abase0 + (size_t)ch * 128;
+            char* dst = smem + LDS_ACT + (ch & 1) * 32768;
+#pragma unroll
+            for (int i = 0; i < 4; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
+        };
+
+        issue_a(0, 0);
+        issue_a(0, 1);
+        issue_w(0);
+        issue_w(1);
+        int pending = 6;  // loads issued after the data of the upcoming step
+        for (int t = 0; t < T_total; t++) {
+            if (pending == 10) wait_vm_barrier<10>();
+            else if (pending == 6) wait_vm_barrier<6>();
+            else wait_vm_barrier<0>();
+            pending = 0;
+            const int ch = t / 3, g = t - ch * 3;
+            if (t + 2 < T_total) {
+                issue_w(t + 2);
+                pending += 6;
+            }
+            if (g < 2 && ch + 1 < nch) {
+                issue_a(ch + 1, g);
+                pending += 4;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ================================ consumer waves ================================
+    const int r = lane & 31, h = lane >> 5;
+    int ph[2], pw[2];
+    bool pvalid[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) {
+        const int p = pb * 32 + r;
+        ph[pb] = p / S;
+        pw[pb] = p - ph[pb] * S;
+        pvalid[pb] = p < S * S;
+    }
+    // activation fragment addressing per tap: byte offset inside the wave's board image, swizzle term
+    int brel[9][2], bx0[9][2];
+    bool bok[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int pb = 0; pb < 2; pb++) {
+            const int hh = ph[pb] + tap / 3 - 1, ww = pw[pb] + tap % 3 - 1;
+            const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
+            const int q = hh * S + ww;
+            bok[tap][pb] = ok;
+            brel[tap][pb] = q * 128;
+            bx0[tap][pb] = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
+        }
+    int arow[2], ax0[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        const int row = cb * 32 + r;
+        arow[cb] = row * 128;
+        ax0[cb] = (h ^ ((row >> 1) & 7)) << 4;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    for (int ch = 0; ch < nch; ch++) {
+        const int abase = LDS_ACT + (ch & 1) * 32768 + wave * 8192;
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            asm volatile("s_barrier" ::: "memory");
+            const int wslab = V2_LDS_W + ((ch * 3 + g) % 3) * V2_SLAB;
+#pragma unroll
+            for (int dxi = 0; dxi < 3; dxi++) {
+                const int tap = g * 3 + dxi;
+                const int wbase = wslab + dxi * 8192;
+                int brow[2];
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) brow[pb] = bok[tap][pb] ? abase + brel[tap][pb] : LDS_ZERO;
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    frag a[2], b[2];
+#pragma unroll
+                    for (int cb = 0; cb < 2; cb++)
+                        a[cb] = *reinterpret_cast<const frag*>(smem + wbase + arow[cb] + (ax0[cb] ^ (ks << 5)));
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++)
+                        b[pb] = *reinterpret_cast<const frag*>(smem + brow[pb] + (bx0[tap][pb] ^ (ks << 5)));
+#pragma unroll
+                    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+                        for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(a[cb], b[pb], acc[cb][pb]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue (identical to v1) ----
+    const size_t board = (size_t)(b0 + wave);
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int pb = 0; pb < 2; pb++) {
+            const int p = pb * 32 + r;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = cout0 + cb * 32 + g * 8 + h * 4;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
+                const size_t off = (board * SLOTS + p) * (size_t)cout + co;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
+                if (HAS_RES) {
+                    T rv[4];
+                    if (sizeof(T) == 2)
+                        *reinterpret_cast<uint64_t*>(rv) = *reinterpret_cast<const uint64_t*>(res + off);
+                    else
+                        *reinterpret_cast<f32x4*>(rv) = *reinterpret_cast<const f32x4*>(res + off);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = v[i] + (float)rv[i];
+                }
+                T ov[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float y = v[i] > 0.0f ? v[i] : 0.0f;
+                    if (!pvalid[pb]) y = 0.0f;
+                    ov[i] = (T)y;
+                }
+                if (sizeof(T) == 2)
+                    *reinterpret_cast<uint64_t*>(out + off) = *reinterpret_cast<uint64_t*>(ov);
+                else
+                    *reinterpret_cast<f32x4*>(out + off) = *reinterpret_cast<f32x4*>(ov);
+            }
+        }
+}
+
+int g_conv_impl = 2;  // 1 = single-role kernel above, 2 = loader/consumer kernel
+void set_conv_impl(int v) { g_conv_impl = v; }
+
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st) {
     const dim3 grid((bpad / BOARDS_PER_WG) * (cout / COUT_PER_WG)), block(256);
+#define CATTUS_LAUNCH_CONV2(T, R)                                                                         \
+    do {                                                                                                  \
+        static bool attr_set = false;                                                                     \
+        if (!attr_set) {                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
+            attr_set = true;                                                                              \
+        }                                                                                                 \
+        hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R>), grid, dim3(512), V2_LDS_TOTAL, st, (const T*)in, \
+                           (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S);       \
+    } while (0)
+    if (g_conv_impl == 2) {
+        if (act == Act::BF16) {
+            if (res) CATTUS_LAUNCH_CONV2(__bf16, true);
+            else CATTUS_LAUNCH_CONV2(__bf16, false);
+        } else {
+            if (res) CATTUS_LAUNCH_CONV2(float, true);
+            else CATTUS_LAUNCH_CONV2(float, false);
+        }
+        return;
+    }
+#undef CATTUS_LAUNCH_CONV2
 #define CATTUS_LAUNCH_CONV(T, R)                                                                          \
     do {                                                                                                  \
         static bool attr_set = false;                                                                     \
