@@ -155,7 +155,10 @@ struct cattus_eval {
 
     ConvLayer stem;
     std::vector<std::unique_ptr<ConvLayer>> c1, c2;
+    // heads: generic path keeps f32 [k][n]-transposed FC weights for the SIMT kernels; the tuned path
+    // keeps K-contiguous, zero-padded matrices in the tower element type for the MFMA head GEMMs
     DevBuf head_w, head_b, w1t, b1, w2, b2, wpt, bp;
+    uint32_t kvp = 0, kpp = 0;  // padded K of the value / policy FC (tuned path)
 
     DevBuf d_planes, x0, a, t, y, hv, h1, d_policy, d_value;
     PinnedBuf h_planes, h_policy, h_value;
@@ -264,21 +267,42 @@ int build(cattus_eval* e, const float* p) {
     memcpy(hw_w.data() + fv.w.size(), fp.w.data(), fp.w.size() * 4);
     memcpy(hw_b.data(), fv.b.data(), fv.b.size() * 4);
     memcpy(hw_b.data() + fv.b.size(), fp.b.data(), fp.b.size() * 4);
-    if ((rc = e->head_w.upload(hw_w.data(), hw_w.size() * 4))) return rc;
-    if ((rc = e->head_b.upload(hw_b.data(), hw_b.size() * 4))) return rc;
-
     const uint32_t kv = d.vhc * hw, kp = d.phc * hw;
-    std::vector<float> w1t((size_t)kv * FC_HIDDEN), wpt((size_t)kp * d.moves);
-    for (uint32_t j = 0; j < FC_HIDDEN; j++)
-        for (uint32_t k = 0; k < kv; k++) w1t[(size_t)k * FC_HIDDEN + j] = fc1_w[(size_t)j * kv + k];
-    for (uint32_t m = 0; m < d.moves; m++)
-        for (uint32_t k = 0; k < kp; k++) wpt[(size_t)k * d.moves + m] = pfc_w[(size_t)m * kp + k];
-    if ((rc = e->w1t.upload(w1t.data(), w1t.size() * 4))) return rc;
+    if ((rc = e->head_b.upload(hw_b.data(), hw_b.size() * 4))) return rc;
     if ((rc = e->b1.upload(fc1_b, FC_HIDDEN * 4))) return rc;
     if ((rc = e->w2.upload(fc2_w, FC_HIDDEN * 4))) return rc;
     if ((rc = e->b2.upload(fc2_b, 4))) return rc;
-    if ((rc = e->wpt.upload(wpt.data(), wpt.size() * 4))) return rc;
     if ((rc = e->bp.upload(pfc_b, d.moves * 4))) return rc;
+    if (e->tuned) {
+        // K-contiguous matrices, K padded to 16 with zeros (zero terms do not change an fmaf chain)
+        const uint32_t ocn = d.vhc + d.phc, F_ = F;
+        e->kvp = (kv + 15) / 16 * 16;
+        e->kpp = (kp + 15) / 16 * 16;
+        const uint32_t m32 = (d.moves + 31) / 32 * 32;
+        std::vector<float> cw((size_t)32 * F_, 0.0f), w1((size_t)FC_HIDDEN * e->kvp, 0.0f), wp((size_t)m32 * e->kpp, 0.0f);
+        memcpy(cw.data(), hw_w.data(), (size_t)ocn * F_ * 4);
+        for (uint32_t j = 0; j < FC_HIDDEN; j++) memcpy(&w1[(size_t)j * e->kvp], &fc1_w[(size_t)j * kv], kv * 4);
+        for (uint32_t m = 0; m < d.moves; m++) memcpy(&wp[(size_t)m * e->kpp], &pfc_w[(size_t)m * kp], kp * 4);
+        auto upload_t = [&](DevBuf& buf, const std::vector<float>& v) -> int {
+            if (e->act == Act::F32) return buf.upload(v.data(), v.size() * 4);
+            std::vector<uint16_t> hb(v.size());
+            for (size_t i = 0; i < v.size(); i++) hb[i] = f32_to_bf16(v[i]);
+            return buf.upload(hb.data(), hb.size() * 2);
+        };
+        if ((rc = upload_t(e->head_w, cw))) return rc;
+        if ((rc = upload_t(e->w1t, w1))) return rc;
+        if ((rc = upload_t(e->wpt, wp))) return rc;
+    } else {
+        std::vector<float> w1t((size_t)kv * FC_HIDDEN), wpt((size_t)kp * d.moves);
+        for (uint32_t j = 0; j < FC_HIDDEN; j++)
+            for (uint32_t k = 0; k < kv; k++) w1t[(size_t)k * FC_HIDDEN + j] = fc1_w[(size_t)j * kv + k];
+        for (uint32_t m = 0; m < d.moves; m++)
+            for (uint32_t k = 0; k < kp; k++) wpt[(size_t)k * d.moves + m] = pfc_w[(size_t)m * kp + k];
+        if ((rc = e->head_w.upload(hw_w.data(), hw_w.size() * 4))) return rc;
+        if ((rc = e->w1t.upload(w1t.data(), w1t.size() * 4))) return rc;
+        if ((rc = e->wpt.upload(wpt.data(), wpt.size() * 4))) return rc;
+        e->kvp = kv, e->kpp = kp;
+    }
 
     // activations
     const size_t bp_ = e->bpad, B = e->cfg.max_batch;
@@ -289,7 +313,8 @@ int build(cattus_eval* e, const float* p) {
     if ((rc = e->a.alloc(bp_ * slots * F * esz))) return rc;
     if ((rc = e->t.alloc(bp_ * slots * F * esz))) return rc;
     if ((rc = e->y.alloc(bp_ * slots * F * esz))) return rc;
-    if ((rc = e->hv.alloc(bp_ * (kv + kp) * 4))) return rc;
+    if ((rc = e->hv.alloc(bp_ * (e->kvp + e->kpp) * esz))) return rc;
+    HIP_TRY(hipMemset(e->hv.p, 0, bp_ * (e->kvp + e->kpp) * esz));  // pad columns must read as zero
     if ((rc = e->h1.alloc(bp_ * FC_HIDDEN * 4))) return rc;
     if ((rc = e->d_policy.alloc(B * d.moves * 4))) return rc;
     if ((rc = e->d_value.alloc(B * 4))) return rc;
@@ -350,18 +375,23 @@ int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float*
             std::swap(a, y);
         }
     }
-    TowerView tv;
-    tv.x = a;
-    if (e->tuned) {
-        tv.act = e->act, tv.sb = SLOTS * F, tv.sk = 1, tv.sp = F;
-    } else {
-        tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;
-    }
     const uint32_t kv = d.vhc * hw, kp = d.phc * hw;
-    launch_head_conv1x1(tv, e->head_w.as<float>(), e->head_b.as<float>(), n, F, d.vhc + d.phc, hw, e->hv.as<float>(), st);
-    launch_value_fc1(e->hv.as<float>(), kv + kp, e->w1t.as<float>(), e->b1.as<float>(), n, kv, e->h1.as<float>(), st);
-    launch_value_fc2_tanh(e->h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
-    launch_policy_fc(e->hv.as<float>(), kv + kp, kv, e->wpt.as<float>(), e->bp.as<float>(), n, kp, d.moves, d_policy, st);
+    if (e->tuned) {
+        HeadsMfma hd{};
+        hd.conv_w = e->head_w.p, hd.conv_b = e->head_b.as<float>(), hd.hv = e->hv.p;
+        hd.w1 = e->w1t.p, hd.b1 = e->b1.as<float>(), hd.h1 = e->h1.as<float>();
+        hd.wp = e->wpt.p, hd.bp = e->bp.as<float>(), hd.policy = d_policy;
+        hd.hw = hw, hd.vhc = d.vhc, hd.phc = d.phc, hd.kvp = e->kvp, hd.kpp = e->kpp, hd.M = d.moves;
+        launch_heads_mfma(e->act, a, n, F, hd, st);
+        launch_value_fc2_tanh(e->h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
+    } else {
+        TowerView tv;
+        tv.x = a, tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;
+        launch_head_conv1x1(tv, e->head_w.as<float>(), e->head_b.as<float>(), n, F, d.vhc + d.phc, hw, e->hv.as<float>(), st);
+        launch_value_fc1(e->hv.as<float>(), kv + kp, e->w1t.as<float>(), e->b1.as<float>(), n, kv, e->h1.as<float>(), st);
+        launch_value_fc2_tanh(e->h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
+        launch_policy_fc(e->hv.as<float>(), kv + kp, kv, e->wpt.as<float>(), e->bp.as<float>(), n, kp, d.moves, d_policy, st);
+    }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(CATTUS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
     return CATTUS_OK;
@@ -491,7 +521,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if (e->cfg.flush_us == 0) e->cfg.flush_us = 200;
     e->device = cfg->device;
     e->hw = d.board * d.board;
-    e->tuned = d.board <= 8 && d.filters % COUT_PER_WG == 0;
+    e->tuned = d.board <= 8 && d.filters % COUT_PER_WG == 0 && d.vhc + d.phc <= 32;
     e->act = cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16 : Act::F32;
     if (!e->tuned && e->act == Act::BF16)
         return fail(CATTUS_E_UNSUPPORTED, "bf16 tower needs filters %% 64 == 0 and board <= 8 (got %u filters, board %u)", d.filters, d.board);

@@ -38,7 +38,26 @@ void set_conv_impl(int v);
 void launch_conv3x3_generic(const float* in, const float* w, const float* bias, const float* res, float* out,
                             uint32_t b, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st);
 
-// ---- K3-K5: heads (f32 accumulate, k-ascending fmaf chains) -------------------------------
+// ---- K3-K5: heads on MFMA (tuned tower layout) ----------------------------------------------
+// All matrices are in the tower element type `act` with K contiguous and zero-padded:
+//   conv_w [32][F] (value rows, then policy rows, rest zero), conv_b [vhc+phc] f32,
+//   hv [nb][kvp+kpp] (value part at 0, policy part at kvp; pad columns stay zero),
+//   w1 [128][kvp], b1 [128] f32, h1 [nb][128] f32, wp [round32(M)][kpp], bp [M] f32, policy [nb][M] f32.
+struct HeadsMfma {
+    const void* conv_w;
+    const float* conv_b;
+    void* hv;
+    const void* w1;
+    const float* b1;
+    float* h1;
+    const void* wp;
+    const float* bp;
+    float* policy;
+    uint32_t hw, vhc, phc, kvp, kpp, M;
+};
+void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, const HeadsMfma& hd, hipStream_t st);
+
+// ---- K3-K5: heads, SIMT f32 (generic tower layout), same term order as the MFMA path ------
 // Tower output addressing: element (b, k, p) at  x[b*sb + k*sk + p*sp]  (elements of type `act`).
 struct TowerView {
     const void* x;

@@ -347,9 +347,12 @@ __global__ void __launch_bounds__(256, 1)
 // no global memory instruction and almost no address arithmetic inside the loop.
 //
 // The fmaf-chain order per output element is unchanged: chunk -> tap 0..8 -> k (0,4,1,5,2,6,3,7).
+// LDS map: weight ring first so that (ring slot, tap) offsets fold into ds_read immediates.
 constexpr int V2_SLAB = 3 * 8192;
-constexpr int V2_LDS_W = LDS_ACT + 2 * 32768;
-constexpr int V2_LDS_TOTAL = V2_LDS_W + 3 * V2_SLAB;  // 139392 B
+constexpr int V2_LDS_W = 0;                           // 3 x 24 KiB
+constexpr int V2_LDS_ZERO = 3 * V2_SLAB;              // 128 B of zeros
+constexpr int V2_LDS_ACT = V2_LDS_ZERO + 128;         // 2 x 32 KiB
+constexpr int V2_LDS_TOTAL = V2_LDS_ACT + 2 * 32768;  // 139392 B
 
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(512, 2)
     const int cout0 = (logical % ncb) * COUT_PER_WG;
     const int b0 = (logical / ncb) * BOARDS_PER_WG;
 
-    if (tid < 8) reinterpret_cast<f32x4*>(smem + LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
 
     const int nch = cin / KC;
@@ -419,7 +422,7 @@ __global__ void __launch_bounds__(512, 2)
         };
         auto issue_a = [&](int ch, int g) {  // half g of activation chunk ch -> buffer ch & 1
             const char* src = abase0 + (size_t)ch * 128;
-            char* dst = smem + LDS_ACT + (ch & 1) * 32768;
+            char* dst = smem + V2_LDS_ACT + (ch & 1) * 32768;
 #pragma unroll
             for (int i = 0; i < 4; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
         };
@@ -459,26 +462,13 @@ __global__ void __launch_bounds__(512, 2)
         pw[pb] = p - ph[pb] * S;
         pvalid[pb] = p < S * S;
     }
-    // activation fragment addressing per tap: byte offset inside the wave's board image, swizzle term
-    int brel[9][2], bx0[9][2];
-    bool bok[9][2];
-#pragma unroll
-    for (int tap = 0; tap < 9; tap++)
-#pragma unroll
-        for (int pb = 0; pb < 2; pb++) {
-            const int hh = ph[pb] + tap / 3 - 1, ww = pw[pb] + tap % 3 - 1;
-            const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
-            const int q = hh * S + ww;
-            bok[tap][pb] = ok;
-            brel[tap][pb] = q * 128;
-            bx0[tap][pb] = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
-        }
-    int arow[2], ax0[2];
+    // weight fragment address per (k-slice, cout block): loop-invariant; ring slot and tap are immediates
+    int aaddr[4][2];
 #pragma unroll
     for (int cb = 0; cb < 2; cb++) {
         const int row = cb * 32 + r;
-        arow[cb] = row * 128;
-        ax0[cb] = (h ^ ((row >> 1) & 7)) << 4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) aaddr[ks][cb] = V2_LDS_W + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4);
     }
 
     f32x16 acc[2][2];
@@ -489,33 +479,57 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
+    // A step is 12 fragment stages (3 taps x 4 k-slices); each stage = 2 weight + 2 activation
+    // fragments feeding 4 MFMAs.  Fragments are read two stages ahead of the MFMAs that consume them
+    // (3-deep register ring) so the LDS latency hides under the 8 MFMAs in between.
+    constexpr int AHEAD = 2, RING = 3;
+    int opaque = 0;
     for (int ch = 0; ch < nch; ch++) {
-        const int abase = LDS_ACT + (ch & 1) * 32768 + wave * 8192;
+        const int abase = V2_LDS_ACT + (ch & 1) * 32768 + wave * 8192;
 #pragma unroll
         for (int g = 0; g < 3; g++) {
-            asm volatile("s_barrier" ::: "memory");
-            const int wslab = V2_LDS_W + ((ch * 3 + g) % 3) * V2_SLAB;
+            // all fragment reads of the previous step have returned before the loaders may reuse its slab
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // keep the per-step activation addresses from being hoisted out of the chunk loop (72 VGPRs)
+            asm volatile("" : "+v"(opaque));
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int wslab = g * V2_SLAB;  // ring slot of step ch*3+g is g
+            int baddr[3][2][4];
 #pragma unroll
-            for (int dxi = 0; dxi < 3; dxi++) {
-                const int tap = g * 3 + dxi;
-                const int wbase = wslab + dxi * 8192;
-                int brow[2];
+            for (int dxi = 0; dxi < 3; dxi++)
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) brow[pb] = bok[tap][pb] ? abase + brel[tap][pb] : LDS_ZERO;
+                for (int pb = 0; pb < 2; pb++) {
+                    const int hh = ph[pb] + (g - 1) + opaque, ww = pw[pb] + dxi - 1;
+                    const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
+                    const int q = hh * S + ww;
+                    const int rowa = ok ? abase + q * 128 : V2_LDS_ZERO;
+                    const int x0 = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    frag a[2], b[2];
-#pragma unroll
-                    for (int cb = 0; cb < 2; cb++)
-                        a[cb] = *reinterpret_cast<const frag*>(smem + wbase + arow[cb] + (ax0[cb] ^ (ks << 5)));
-#pragma unroll
-                    for (int pb = 0; pb < 2; pb++)
-                        b[pb] = *reinterpret_cast<const frag*>(smem + brow[pb] + (bx0[tap][pb] ^ (ks << 5)));
-#pragma unroll
-                    for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-                        for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(a[cb], b[pb], acc[cb][pb]);
+                    for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
                 }
+            frag fa[RING][2], fb[RING][2];
+            auto load_stage = [&](int i, frag (&a)[2], frag (&b)[2]) {
+                const int dxi = i >> 2, ks = i & 3;
+#pragma unroll
+                for (int cb = 0; cb < 2; cb++)
+                    a[cb] = *reinterpret_cast<const frag*>(smem + aaddr[ks][cb] + (wslab + dxi * 8192));
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][ks]);
+            };
+#pragma unroll
+            for (int i = 0; i < AHEAD; i++) load_stage(i, fa[i % RING], fb[i % RING]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * AHEAD, 0);
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                if (i + AHEAD < 12) load_stage(i + AHEAD, fa[(i + AHEAD) % RING], fb[(i + AHEAD) % RING]);
+#pragma unroll
+                for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
+                // pin the issue order: this stage's look-ahead reads, then its MFMAs
+                if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
             }
         }
     }
@@ -652,6 +666,105 @@ void launch_conv3x3_generic(const float* in, const float* w, const float* bias, 
 // ------------------------------------------------------------------------------------------
 // K3-K5: heads
 // ------------------------------------------------------------------------------------------
+// Every dot product of the heads runs over k in 8-groups ascending and 0,4,1,5,2,6,3,7 inside a
+// group -- the order an MFMA lane pair (k = 4h + j) produces -- in the MFMA kernels, in the SIMT
+// kernels of the generic path, and in the CPU oracle alike.
+__device__ __forceinline__ uint32_t kperm(uint32_t kk) { return (kk & ~7u) + ((kk & 1u) << 2) + ((kk & 7u) >> 1); }
+
+// ---- MFMA path: D[i][j] = sum_k P[i][k] * Q[j][k], P and Q row-major with K contiguous -----
+// One wave per 32x32 tile, fragments straight from global memory (the operands are small and
+// L2-resident); 4 waves of a block take 4 neighbouring j-tiles.  K % (128/sizeof(T)/4... ) see host.
+enum { EPI_HEADCONV = 0, EPI_FC1 = 1, EPI_POLICY = 2 };
+
+struct HeadEpi {
+    const float* bias;
+    void* out;
+    uint32_t hw, vhc, ocn, hvs, kvp, M;
+};
+
+template <typename T, int EPI>
+__global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P, uint32_t ldp, uint32_t I,
+                                                        const T* __restrict__ Q, uint32_t ldq, uint32_t J, uint32_t K,
+                                                        HeadEpi ep) {
+    typedef typename Mfma<T>::frag frag;
+    constexpr uint32_t KSTEP = 32 / sizeof(T);  // k per MFMA stage: 16 (bf16) or 8 (f32)
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const uint32_t i0 = blockIdx.y * 32, j0 = (blockIdx.x * 4 + wave) * 32;
+    if (j0 >= J) return;
+    const uint32_t pi = min(i0 + r, I - 1), qj = min(j0 + r, J - 1);
+    const T* pp = P + (size_t)pi * ldp + h * (KSTEP / 2);
+    const T* qp = Q + (size_t)qj * ldq + h * (KSTEP / 2);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+    for (uint32_t k = 0; k < K; k += 4 * KSTEP) {
+        frag a[4], b[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+            if (k + u * KSTEP < K) {
+                a[u] = *reinterpret_cast<const frag*>(pp + k + u * KSTEP);
+                b[u] = *reinterpret_cast<const frag*>(qp + k + u * KSTEP);
+            }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+            if (k + u * KSTEP < K) Mfma<T>::mac(a[u], b[u], acc);
+    }
+    const uint32_t j = j0 + r;
+    if (j >= J) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const uint32_t i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i >= I) continue;
+        if constexpr (EPI == EPI_HEADCONV) {
+            // i = head channel (value rows first), j = tower row b*64 + p
+            const uint32_t bb = j / SLOTS, p = j % SLOTS;
+            if (i >= ep.ocn || p >= ep.hw) continue;
+            const float y = acc[e] + ep.bias[i];
+            const uint32_t col = i < ep.vhc ? i * ep.hw + p : ep.kvp + (i - ep.vhc) * ep.hw + p;
+            reinterpret_cast<T*>(ep.out)[(size_t)bb * ep.hvs + col] = (T)(y > 0.0f ? y : 0.0f);
+        } else if constexpr (EPI == EPI_FC1) {
+            const float y = acc[e] + ep.bias[j];
+            reinterpret_cast<float*>(ep.out)[(size_t)i * 128 + j] = y > 0.0f ? y : 0.0f;
+        } else {
+            float y = acc[e] + ep.bias[j];
+            // non-finite logits -> f32::MIN (reference: engine/src/net/mod.rs:56-61)
+            if (!(__builtin_fabsf(y) <= 3.40282347e+38f)) y = -3.40282347e+38f;
+            reinterpret_cast<float*>(ep.out)[(size_t)i * ep.M + j] = y;
+        }
+    }
+}
+
+template <int EPI>
+static void launch_head_gemm(Act act, const void* P, uint32_t ldp, uint32_t I, const void* Q, uint32_t ldq, uint32_t J,
+                             uint32_t K, const HeadEpi& ep, hipStream_t st) {
+    if (!I || !J) return;
+    const dim3 grid(((J + 31) / 32 + 3) / 4, (I + 31) / 32), block(256);
+    if (act == Act::BF16)
+        hipLaunchKernelGGL((head_gemm_kernel<__bf16, EPI>), grid, block, 0, st, (const __bf16*)P, ldp, I, (const __bf16*)Q, ldq,
+                           J, K, ep);
+    else
+        hipLaunchKernelGGL((head_gemm_kernel<float, EPI>), grid, block, 0, st, (const float*)P, ldp, I, (const float*)Q, ldq, J,
+                           K, ep);
+}
+
+void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, const HeadsMfma& hd, hipStream_t st) {
+    HeadEpi ep{};
+    ep.hw = hd.hw, ep.vhc = hd.vhc, ep.ocn = hd.vhc + hd.phc, ep.hvs = hd.kvp + hd.kpp, ep.kvp = hd.kvp, ep.M = hd.M;
+    // K3: both 1x1 convs in one GEMM: i = head channel, j = tower row
+    ep.bias = hd.conv_b, ep.out = hd.hv;
+    launch_head_gemm<EPI_HEADCONV>(act, hd.conv_w, F, 32, tower, F, nb * SLOTS, F, ep, st);
+    // K4: value FC1 (+ReLU): i = leaf, j = hidden unit
+    const size_t esz = act == Act::BF16 ? 2 : 4;
+    ep.bias = hd.b1, ep.out = hd.h1;
+    launch_head_gemm<EPI_FC1>(act, hd.hv, ep.hvs, nb, hd.w1, hd.kvp, 128, hd.kvp, ep, st);
+    // K5: policy FC: i = leaf, j = move
+    ep.bias = hd.bp, ep.out = hd.policy;
+    launch_head_gemm<EPI_POLICY>(act, (const char*)hd.hv + (size_t)hd.kvp * esz, ep.hvs, nb, hd.wp, hd.kpp, hd.M, hd.kpp, ep,
+                                 st);
+}
+
+// ---- SIMT path (generic tower layout, any shape), same term order ---------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) head_conv1x1_kernel(const T* __restrict__ x, uint32_t sb, uint32_t sk, uint32_t sp,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
@@ -663,7 +776,11 @@ __global__ void __launch_bounds__(256) head_conv1x1_kernel(const T* __restrict__
     const T* xp = x + (size_t)b * sb + (size_t)p * sp;
     const float* wr = w + (size_t)oc * F;
     float acc = 0.0f;
-    for (uint32_t k = 0; k < F; k++) acc = __builtin_fmaf(wr[k], (float)xp[(size_t)k * sk], acc);
+    const uint32_t F8 = (F + 7) & ~7u;
+    for (uint32_t kk = 0; kk < F8; kk++) {
+        const uint32_t k = kperm(kk);
+        if (k < F) acc = __builtin_fmaf(wr[k], (float)xp[(size_t)k * sk], acc);
+    }
     const float y = acc + bias[oc];
     hv[e] = y > 0.0f ? y : 0.0f;
 }
@@ -687,7 +804,11 @@ __global__ void __launch_bounds__(128) value_fc1_kernel(const float* __restrict_
     const uint32_t b = blockIdx.x, j = threadIdx.x;
     const float* x = hv + (size_t)b * hv_stride;
     float acc = 0.0f;
-    for (uint32_t k = 0; k < K; k++) acc = __builtin_fmaf(w1t[(size_t)k * 128 + j], x[k], acc);
+    const uint32_t K8 = (K + 7) & ~7u;
+    for (uint32_t kk = 0; kk < K8; kk++) {
+        const uint32_t k = kperm(kk);
+        if (k < K) acc = __builtin_fmaf(w1t[(size_t)k * 128 + j], x[k], acc);
+    }
     const float y = acc + b1[j];
     h1[(size_t)b * 128 + j] = y > 0.0f ? y : 0.0f;
 }
@@ -745,7 +866,10 @@ __global__ void __launch_bounds__(256) value_fc2_tanh_kernel(const float* __rest
     if (b >= nb) return;
     const float* x = h1 + (size_t)b * 128;
     float acc = 0.0f;
-    for (int j = 0; j < 128; j++) acc = __builtin_fmaf(w2[j], x[j], acc);
+    for (uint32_t kk = 0; kk < 128; kk++) {
+        const uint32_t j = kperm(kk);
+        acc = __builtin_fmaf(w2[j], x[j], acc);
+    }
     value[b] = tanh_exact(acc + b2[0]);
 }
 
@@ -773,7 +897,10 @@ __global__ void __launch_bounds__(256) policy_fc_kernel(const float* __restrict_
     float acc[PFC_ROWS];
 #pragma unroll
     for (int rr = 0; rr < PFC_ROWS; rr++) acc[rr] = 0.0f;
-    for (uint32_t k = 0; k < K; k++) {
+    const uint32_t K8 = (K + 7) & ~7u;
+    for (uint32_t kk = 0; kk < K8; kk++) {
+        const uint32_t k = kperm(kk);
+        if (k >= K) continue;
         const float wv = wpt[(size_t)k * M + m];
 #pragma unroll
         for (int rr = 0; rr < PFC_ROWS; rr++) acc[rr] = __builtin_fmaf(wv, xs[rr * K + k], acc[rr]);

@@ -27,7 +27,8 @@
  *       for k in chunk in the order 0,4,1,5,2,6,3,7, 8,12,9,13,...
  *     with zero padding outside the board, then  y = acc + b'
  *     (+ residual input, then ReLU).
- *   - 1x1 conv / linear layers = fmaf chain over k ascending, then + bias.
+ *   - 1x1 conv / linear layers = fmaf chain over k in the same 8-group order
+ *     (0,4,1,5,2,6,3,7, 8,12,...), then + bias.
  *   - tanh: oracle_tanhf below (only + - * / fmaf and exponent bit edits).
  * Build with -ffp-contract=off so no other fusion happens.
  */
@@ -346,13 +347,20 @@ static void conv3x3(const conv3_layer *L, const float *in, const float *res, flo
     else conv3x3_scalar(L, in, res, out, S);
 }
 
+/* k index of the kk-th term of a dot product: 8-groups ascending, 0,4,1,5,2,6,3,7 inside a group */
+static inline uint32_t kperm(uint32_t kk) { return (kk & ~7u) + (uint32_t)KPERM[kk & 7]; }
+
 /* 1x1 conv + folded BN + ReLU: out[oc][p] = relu(chain_k(w[oc][k]*in[k][p]) + b[oc]) */
 HOT static void conv1x1_relu(const float *w, const float *b, uint32_t oc_n, uint32_t F, uint32_t hw,
                              const float *in, float *out) {
+    const uint32_t F8 = (F + 7) & ~7u;
     for (uint32_t oc = 0; oc < oc_n; oc++)
         for (uint32_t p = 0; p < hw; p++) {
             float acc = 0.0f;
-            for (uint32_t k = 0; k < F; k++) acc = __builtin_fmaf(w[oc * F + k], in[k * hw + p], acc);
+            for (uint32_t kk = 0; kk < F8; kk++) {
+                const uint32_t k = kperm(kk);
+                if (k < F) acc = __builtin_fmaf(w[oc * F + k], in[k * hw + p], acc);
+            }
             float y = acc + b[oc];
             out[oc * hw + p] = y > 0.0f ? y : 0.0f;
         }
@@ -361,10 +369,14 @@ HOT static void conv1x1_relu(const float *w, const float *b, uint32_t oc_n, uint
 /* y[j] = chain_k(w[j][k]*x[k]) + b[j] */
 HOT static void linear(const float *w, const float *b, uint32_t out_n, uint32_t in_n, const float *x,
                        float *y) {
+    const uint32_t n8 = (in_n + 7) & ~7u;
     for (uint32_t j = 0; j < out_n; j++) {
         float acc = 0.0f;
         const float *wr = w + (size_t)j * in_n;
-        for (uint32_t k = 0; k < in_n; k++) acc = __builtin_fmaf(wr[k], x[k], acc);
+        for (uint32_t kk = 0; kk < n8; kk++) {
+            const uint32_t k = kperm(kk);
+            if (k < in_n) acc = __builtin_fmaf(wr[k], x[k], acc);
+        }
         y[j] = acc + b[j];
     }
 }
