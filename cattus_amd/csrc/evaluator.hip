@@ -335,43 +335,38 @@ int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float*
                     hipStream_t st, TowerTimer* tt = nullptr) {
     const cattus_net_desc& d = e->d;
     const uint32_t F = d.filters, hw = e->hw, S = d.board, w64 = e->cfg.plane_words;
-    auto mark = [&](bool begin) {
-        if (!tt) return;
-        if (begin && tt->used + 2 > tt->ev.size()) return;
-        (void)hipEventRecord(tt->ev[tt->used++], st);
+    // timing pass: each tower launch gets its own (start, stop) event pair stamped by the kernel itself
+    auto ev = [&](bool stop) -> hipEvent_t {
+        if (!tt || tt->used >= tt->ev.size()) return nullptr;
+        (void)stop;
+        return tt->ev[tt->used++];
     };
     void *a = e->a.p, *t = e->t.p, *y = e->y.p;
     uint32_t nb = n;
     if (e->tuned) {
         nb = (n + BOARDS_PER_WG - 1) / BOARDS_PER_WG * BOARDS_PER_WG;
         launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, e->x0.p, st);
-        mark(true);
-        launch_conv3x3_mfma(e->act, e->x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, F, S, st);
-        mark(false);
+        hipEvent_t s0 = ev(false), s1 = ev(true);
+        launch_conv3x3_mfma(e->act, e->x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, F, S, st, s0, s1);
         for (uint32_t i = 0; i < d.blocks; i++) {
-            mark(true);
-            launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, F, F, S, st);
-            mark(false);
-            mark(true);
-            launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, F, F, S, st);
-            mark(false);
+            s0 = ev(false), s1 = ev(true);
+            launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, F, F, S, st, s0, s1);
+            s0 = ev(false), s1 = ev(true);
+            launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, F, F, S, st, s0, s1);
             std::swap(a, y);
         }
     } else {
         launch_planes_to_tensor_nchw(d_planes, n, d.planes, w64, S, n, e->x0.as<float>(), st);
-        mark(true);
+        hipEvent_t s0 = ev(false), s1 = ev(true);
         launch_conv3x3_generic(e->x0.as<float>(), e->stem.w.as<float>(), e->stem.b.as<float>(), nullptr, (float*)a, n,
-                               d.planes, F, S, st);
-        mark(false);
+                               d.planes, F, S, st, s0, s1);
         for (uint32_t i = 0; i < d.blocks; i++) {
-            mark(true);
+            s0 = ev(false), s1 = ev(true);
             launch_conv3x3_generic((float*)a, e->c1[i]->w.as<float>(), e->c1[i]->b.as<float>(), nullptr, (float*)t, n, F,
-                                   F, S, st);
-            mark(false);
-            mark(true);
+                                   F, S, st, s0, s1);
+            s0 = ev(false), s1 = ev(true);
             launch_conv3x3_generic((float*)t, e->c2[i]->w.as<float>(), e->c2[i]->b.as<float>(), (float*)a, (float*)y, n,
-                                   F, F, S, st);
-            mark(false);
+                                   F, F, S, st, s0, s1);
             std::swap(a, y);
         }
     }

@@ -27,8 +27,10 @@ void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C
 // ---- K1/K2: 3x3 conv + folded BN (+ residual) + ReLU, MFMA, NHWC -------------------------
 // in [bpad][64][cin], w [9][cout][cin], bias [cout] f32, res/out [bpad][64][cout].
 // Requires bpad % 4 == 0, cin % kc == 0, cout % 64 == 0, S <= 8.
+// ev_start / ev_stop (optional): events stamped with the kernel's own begin / end time.
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
-                         uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st);
+                         uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // Selects the tower kernel variant (1 or 2); for A/B measurements only.
 void set_conv_impl(int v);
@@ -36,7 +38,8 @@ void set_conv_impl(int v);
 // Generic f32 NCHW direct conv for shapes the MFMA kernel does not cover (any S <= 11, any C).
 // in [b][cin][hw], w [9][cout][cin], out [b][cout][hw]; same summation order as the MFMA f32 kernel.
 void launch_conv3x3_generic(const float* in, const float* w, const float* bias, const float* res, float* out,
-                            uint32_t b, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st);
+                            uint32_t b, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
+                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- K3-K5: heads on MFMA (tuned tower layout) ----------------------------------------------
 // All matrices are in the tower element type `act` with K contiguous and zero-padded:

@@ -12,6 +12,8 @@
 // so results are bit-identical across batch sizes, batch compositions and to the CPU oracle.
 #include "kernels.h"
 
+#include <hip/hip_ext.h>
+
 namespace cattus {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -577,7 +579,8 @@ int g_conv_impl = 2;  // 1 = single-role kernel above, 2 = loader/consumer kerne
 void set_conv_impl(int v) { g_conv_impl = v; }
 
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
-                         uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st) {
+                         uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st, hipEvent_t ev_start,
+                         hipEvent_t ev_stop) {
     const dim3 grid((bpad / BOARDS_PER_WG) * (cout / COUT_PER_WG)), block(256);
 #define CATTUS_LAUNCH_CONV2(T, R)                                                                         \
     do {                                                                                                  \
@@ -587,8 +590,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
             attr_set = true;                                                                              \
         }                                                                                                 \
-        hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R>), grid, dim3(512), V2_LDS_TOTAL, st, (const T*)in, \
-                           (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S);       \
+        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R>), grid, dim3(512), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                              (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S); \
     } while (0)
     if (g_conv_impl == 2) {
         if (act == Act::BF16) {
@@ -609,8 +612,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);             \
             attr_set = true;                                                                              \
         }                                                                                                 \
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<T, R>), grid, block, LDS_TOTAL, st, (const T*)in, (const T*)w, bias, \
-                           (const T*)res, (T*)out, (int)cin, (int)cout, (int)S);                          \
+        hipExtLaunchKernelGGL((conv3x3_mfma_kernel<T, R>), grid, block, LDS_TOTAL, st, ev_start, ev_stop, 0, (const T*)in, \
+                              (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S);    \
     } while (0)
     if (act == Act::BF16) {
         if (res) CATTUS_LAUNCH_CONV(__bf16, true);
@@ -656,11 +659,12 @@ __global__ void __launch_bounds__(256) conv3x3_generic_kernel(const float* __res
 }
 
 void launch_conv3x3_generic(const float* in, const float* w, const float* bias, const float* res, float* out,
-                            uint32_t b, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st) {
+                            uint32_t b, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st, hipEvent_t ev_start,
+                            hipEvent_t ev_stop) {
     const uint32_t total = b * cout * S * S;
     if (!total) return;
-    hipLaunchKernelGGL(conv3x3_generic_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, w, bias, res, out,
-                       total, (int)cin, (int)cout, (int)S);
+    hipExtLaunchKernelGGL(conv3x3_generic_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ev_start, ev_stop, 0, in, w,
+                          bias, res, out, total, (int)cin, (int)cout, (int)S);
 }
 
 // ------------------------------------------------------------------------------------------

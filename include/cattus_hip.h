@@ -92,8 +92,9 @@ int cattus_hip_flush(cattus_eval* e);
 int cattus_hip_stats(cattus_eval* e, cattus_stats* out);
 
 /* Average device time in microseconds of one 3x3-conv tower launch over `reps` forwards of n
- * leaves, measured with HIP events recorded around each launch on the evaluator's stream.
- * also returns the number of such launches per forward. */
+ * leaves.  Every launch carries its own start/stop HIP event pair stamped by the kernel dispatch
+ * itself (hipExtLaunchKernelGGL) on the evaluator's stream.  Also returns the number of such
+ * launches per forward. */
 int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, float* avg_launch_us, uint32_t* launches);
 
 /* Stand-alone planes_to_tensor (engine/src/net/mod.rs:121-156): host planes [n][C][plane_words]
