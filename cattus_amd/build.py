@@ -54,8 +54,30 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     return HIP_LIB
 
 
+HOST_LIB = PKG / "libcattus_selfplay.so"
+HOST_DIR = CSRC / "host"
+HOST_SOURCES = [HOST_DIR / "cabi.cpp"]
+HOST_DEPS = HOST_SOURCES + [HOST_DIR / n for n in ("games.h", "chess.h", "mcts.h", "selfplay.h")] + [
+    ROOT / "include" / "cattus_selfplay.h"
+]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-fvisibility=hidden", "-Wall", "-Wextra",
+              "-Wno-unused-parameter"]
+
+
+def build_host(force: bool = False, verbose: bool = False) -> Path:
+    """Compile cattus_amd/libcattus_selfplay.so (games, MCTS, self-play driver; plain C++, no GPU code)."""
+    if force or _stale(HOST_LIB, HOST_DEPS):
+        cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+        cmd = [cxx, *HOST_FLAGS, "-o", str(HOST_LIB), *map(str, HOST_SOURCES), "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force, verbose)
+    build_host(force, verbose)
 
 
 if __name__ == "__main__":

@@ -395,8 +395,9 @@ int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float*
 void account(cattus_eval* e, uint32_t n, double seconds) {
     std::lock_guard<std::mutex> lk(e->stat_mu);
     cattus_stats& s = e->stats;
-    // RunningAverage (reference: engine/src/util/metric.rs:1-20): first sample seeds the average
-    s.run_seconds_ema = s.batches == 0 ? seconds : 0.99 * s.run_seconds_ema + 0.01 * seconds;
+    // RunningAverage::set with epsilon 0.99, starting from 0 (reference: engine/src/util/metric.rs:1-20,
+    // engine/src/net/mod.rs:36): value = (1 - eps) * value + eps * new
+    s.run_seconds_ema = 0.01 * s.run_seconds_ema + 0.99 * seconds;
     s.run_seconds_total += seconds;
     s.batches += 1;
     s.positions += n;

@@ -1,0 +1,377 @@
+// PUCT Monte-Carlo tree search, restated from the reference engine/src/mcts/mod.rs:58-489 so that,
+// given the same leaf evaluations, it visits the same nodes in the same order.
+//
+// The reference search blocks inside ValueFunction::evaluate (mcts/mod.rs:264-268).  Here the
+// search is resumable instead: advance() runs simulations until one needs a network evaluation and
+// returns NEED_EVAL; the caller evaluates the pending leaf (typically batched with the leaves of
+// hundreds of other games on the GPU) and calls deliver().  Simulations of one tree stay strictly
+// sequential, exactly as in the reference (no virtual loss), so visit counts are unchanged.
+//
+// Iteration-order semantics carried over from the reference's graph library (petgraph 0.8.3, not in
+// the reference tree):
+//   * edges(node) yields the most recently added edge first -> children are stored in insertion order
+//     and walked in reverse;
+//   * Iterator::max_by keeps the LAST maximal element -> ties go to the earliest-inserted child;
+//   * remove_all_but_subtree re-adds children in edges() order -> sibling order reverses on every
+//     tree reuse (mcts/mod.rs:303-333).
+#pragma once
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "games.h"
+
+namespace cattus {
+
+// splitmix64 stream: the only randomness of the host side (temperature sampling, Dirichlet noise).
+// The reference uses an unseeded thread RNG there (mcts/mod.rs:415,435), so those paths are not
+// reproducible in the reference either; parity runs use temperature 0 and noise off.
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed = 0x1234) : s(seed) {}
+    uint64_t next() {
+        s += 0x9E3779B97F4A7C15ull;
+        return mix64(s);
+    }
+    double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }  // [0,1)
+    double normal() {
+        double u1 = uniform(), u2 = uniform();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    }
+    double gamma(double alpha) {  // Marsaglia-Tsang; alpha < 1 via the boost trick
+        if (alpha < 1.0) {
+            double u = uniform();
+            if (u < 1e-300) u = 1e-300;
+            return gamma(alpha + 1.0) * std::pow(u, 1.0 / alpha);
+        }
+        const double d = alpha - 1.0 / 3.0, c = 1.0 / std::sqrt(9.0 * d);
+        for (;;) {
+            double x = normal(), v = 1.0 + c * x;
+            if (v <= 0) continue;
+            v = v * v * v;
+            const double u = uniform();
+            if (u < 1.0 - 0.0331 * x * x * x * x) return d * v;
+            if (std::log(u) < 0.5 * x * x + d * (1.0 - v + std::log(v))) return d * v;
+        }
+    }
+};
+
+// TemperaturePolicy (mcts/mod.rs:456-489)
+struct TemperaturePolicy {
+    std::vector<std::pair<size_t, float>> scheduled;  // strictly increasing thresholds
+    float last = 1.0f;
+    float get(size_t move_num) const {
+        for (auto& t : scheduled)
+            if (move_num < t.first) return t.second;
+        return last;
+    }
+};
+
+struct MctsParams {  // mcts/mod.rs:72-79
+    uint32_t sim_num = 100;
+    float explore_factor = 1.41421356f;
+    TemperaturePolicy temperature;
+    float prior_noise_alpha = 0.0f, prior_noise_epsilon = 0.0f;
+};
+
+template <typename G>
+struct Evaluation {  // what ValueFunction::evaluate returns (mcts/value_func.rs:1-11)
+    std::vector<std::pair<typename G::Move, float>> probs;
+    float value = 0.0f;
+};
+
+template <typename G>
+class MctsPlayer {
+   public:
+    typedef typename G::Position Position;
+    typedef typename G::Move Move;
+    enum Step { NEED_EVAL, SEARCH_DONE };
+
+    explicit MctsPlayer(const MctsParams& p, uint64_t seed = 1) : params_(p), rng_(seed) {
+        assert(p.sim_num > 0 && p.explore_factor >= 0 && p.prior_noise_alpha >= 0);
+    }
+
+    // calc_moves_probabilities, first half (mcts/mod.rs:335-358): tree reuse, root creation.
+    void begin_search(const std::vector<Position>& history) {
+        assert(params_.sim_num > 1);  // develop_tree asserts this (mcts/mod.rs:157)
+        const Position& position = history.back();
+        if (has_root_) {
+            const int node = find_node_with_position(position, 3);
+            if (node >= 0) {
+                remove_all_but_subtree((uint32_t)node);
+            } else {
+                nodes_.clear();
+                edges_.clear();
+                has_root_ = false;
+            }
+        }
+        if (!has_root_) {
+            nodes_.push_back(Node(position, 0, 0));
+            root_ = 0;
+            has_root_ = true;
+        }
+        assert(position == nodes_[root_].pos);
+        sims_done_ = 0;
+        waiting_ = false;
+    }
+
+    // develop_tree (mcts/mod.rs:156-196), suspended at the evaluation of an unexpanded leaf.
+    Step advance(const std::vector<Position>& history) {
+        assert(!waiting_);
+        while (sims_done_ < params_.sim_num) {
+            select(path_);
+            const bool repetition = detect_repetition(history, path_);
+            leaf_ = path_.empty() ? root_ : edges_[path_.back()].target;
+            const Status st = nodes_[leaf_].status();
+            if (repetition) {
+                backpropagate(path_, 0.0f);
+            } else if (st.finished) {
+                backpropagate(path_, (float)st.winner);
+            } else {
+                waiting_ = true;
+                return NEED_EVAL;
+            }
+            sims_done_++;
+        }
+        return SEARCH_DONE;
+    }
+    const Position& pending_position() const { return nodes_[leaf_].pos; }
+
+    // second half of a simulation: create_children, root noise, backpropagate (mcts/mod.rs:179-194)
+    void deliver(const Evaluation<G>& ev) {
+        assert(waiting_);
+        create_children(leaf_, ev.probs);
+        if (leaf_ == root_) add_dirichlet_noise(root_);
+        backpropagate(path_, ev.value);
+        sims_done_++;
+        waiting_ = false;
+    }
+
+    // calc_moves_probabilities, second half (mcts/mod.rs:363-379): (move, n / sum n) in edges() order
+    std::vector<std::pair<Move, float>> result() const {
+        std::vector<std::pair<Move, float>> res;
+        const Node& r = nodes_[root_];
+        uint32_t total = 0;
+        for (uint32_t i = r.count; i-- > 0;) total += edges_[r.first + i].n;
+        for (uint32_t i = r.count; i-- > 0;) {
+            const Edge& e = edges_[r.first + i];
+            res.emplace_back(e.m, (float)e.n / (float)total);
+        }
+        return res;
+    }
+    // raw visit counts in the same order (for tests)
+    std::vector<std::pair<Move, uint32_t>> root_visits() const {
+        std::vector<std::pair<Move, uint32_t>> res;
+        const Node& r = nodes_[root_];
+        for (uint32_t i = r.count; i-- > 0;) res.emplace_back(edges_[r.first + i].m, edges_[r.first + i].n);
+        return res;
+    }
+
+    // choose_move_from_probabilities (mcts/mod.rs:387-417)
+    bool choose_move(const std::vector<Position>& history, const std::vector<std::pair<Move, float>>& probs, Move& out) {
+        if (probs.empty()) return false;
+        const float t = params_.temperature.get(history.size() / 2);
+        if (t == 0.0f) {
+            size_t best = 0;  // max_by(total_cmp): the last maximal element wins
+            for (size_t i = 1; i < probs.size(); i++)
+                if (!(probs[best].second > probs[i].second)) best = i;
+            out = probs[best].first;
+            return true;
+        }
+        std::vector<float> w(probs.size());
+        float sum = 0.0f;
+        for (size_t i = 0; i < probs.size(); i++) {
+            w[i] = std::pow(probs[i].second, 1.0f / t);
+            sum += w[i];
+        }
+        double u = rng_.uniform() * (double)sum, accw = 0.0;
+        size_t pick = probs.size() - 1;
+        for (size_t i = 0; i < probs.size(); i++) {
+            accw += w[i];
+            if (u < accw) {
+                pick = i;
+                break;
+            }
+        }
+        out = probs[pick].first;
+        return true;
+    }
+
+    void clear() {
+        nodes_.clear();
+        edges_.clear();
+        has_root_ = false;
+        waiting_ = false;
+    }
+    size_t tree_nodes() const { return nodes_.size(); }
+
+   private:
+    struct Node {
+        Position pos;
+        uint32_t first, count;  // children edges [first, first+count) in insertion order
+        // Position::status() memoised on first use: the reference re-derives it on every visit
+        // (mcts/mod.rs:207), which for chess means a move generation per visited node per simulation.
+        mutable int8_t st_known = 0, st_finished = 0, st_winner = 0;
+        Node(const Position& p, uint32_t f, uint32_t c) : pos(p), first(f), count(c) {}
+        Status status() const {
+            if (!st_known) {
+                const Status s = pos.status();
+                st_known = 1, st_finished = s.finished, st_winner = s.winner;
+            }
+            return Status{(bool)st_finished, st_winner};
+        }
+    };
+    struct Edge {  // MctsEdge (mcts/mod.rs:32-45) + endpoints
+        Move m;
+        float init_score;
+        uint32_t n;
+        float w;
+        uint32_t source, target;
+    };
+
+    // calc_selection_heuristic (mcts/mod.rs:233-244), f32 throughout
+    float heuristic(const Edge& e, uint32_t parent_simcount) const {
+        const float exploit = e.n == 0 ? 0.0f : e.w / (float)e.n;
+        const float explore = params_.explore_factor * e.init_score * (std::sqrt((float)parent_simcount) / (float)(1 + e.n));
+        return exploit + explore;
+    }
+
+    void select(std::vector<uint32_t>& path) const {  // mcts/mod.rs:199-231
+        path.clear();
+        uint32_t node_id = root_;
+        for (;;) {
+            const Node& node = nodes_[node_id];
+            if (node.count == 0 || node.status().finished) return;
+            uint32_t simcount = 1;
+            for (uint32_t i = 0; i < node.count; i++) simcount += edges_[node.first + i].n;
+            // edges() order = newest first; max_by keeps y unless cmp(best, y) == Greater
+            uint32_t best = node.first + node.count - 1;
+            float vbest = heuristic(edges_[best], simcount);
+            for (uint32_t i = node.count - 1; i-- > 0;) {
+                const uint32_t e = node.first + i;
+                const float v = heuristic(edges_[e], simcount);
+                if (!(vbest > v)) {
+                    best = e;
+                    vbest = v;
+                }
+            }
+            path.push_back(best);
+            node_id = edges_[best].target;
+        }
+    }
+
+    bool detect_repetition(const std::vector<Position>& history, const std::vector<uint32_t>& path) const {
+        // mcts/mod.rs:133-154: count equal positions over game history + search path; limit reached -> draw
+        if (G::REPETITION_LIMIT <= 1) return false;
+        seen_.clear();
+        auto visit = [&](const Position& p) {
+            const uint64_t h = p.hash();
+            int cnt = 1;
+            for (auto& s : seen_)
+                if (s.first == h && *s.second == p) cnt++;
+            seen_.emplace_back(h, &p);
+            return cnt >= G::REPETITION_LIMIT;
+        };
+        for (auto& p : history)
+            if (visit(p)) return true;
+        for (uint32_t e : path)
+            if (visit(nodes_[edges_[e].target].pos)) return true;
+        return false;
+    }
+
+    void create_children(uint32_t parent, const std::vector<std::pair<Move, float>>& per_move) {  // mcts/mod.rs:246-262
+        const Position parent_pos = nodes_[parent].pos;
+        nodes_[parent].first = (uint32_t)edges_.size();
+        nodes_[parent].count = (uint32_t)per_move.size();
+        for (auto& mp : per_move) {
+            const uint32_t child = (uint32_t)nodes_.size();
+            nodes_.push_back(Node(parent_pos.moved(mp.first), 0, 0));
+            edges_.push_back(Edge{mp.first, mp.second, 0, 0.0f, parent, child});
+        }
+    }
+
+    void backpropagate(const std::vector<uint32_t>& path, float score) {  // mcts/mod.rs:270-281
+        for (uint32_t e : path) {
+            Edge& edge = edges_[e];
+            edge.n += 1;
+            edge.w += nodes_[edge.source].pos.turn() == PLAYER1 ? score : -score;
+        }
+    }
+
+    int find_node_with_position(const Position& position, uint32_t depth_limit) const {  // mcts/mod.rs:283-301
+        std::vector<uint32_t> layer{root_}, next;
+        for (uint32_t d = 0; d < depth_limit; d++) {
+            next.clear();
+            for (uint32_t node : layer) {
+                if (nodes_[node].pos == position) return (int)node;
+                const Node& nd = nodes_[node];
+                for (uint32_t i = nd.count; i-- > 0;) next.push_back(edges_[nd.first + i].target);
+            }
+            layer.swap(next);
+        }
+        return -1;
+    }
+
+    void remove_all_but_subtree(uint32_t sub_root) {  // mcts/mod.rs:303-333
+        if (root_ == sub_root) return;
+        std::vector<Node> nn;
+        std::vector<Edge> ne;
+        nn.push_back(nodes_[sub_root]);
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{sub_root, 0}};
+        while (!stack.empty()) {
+            const auto [po, pn] = stack.back();
+            stack.pop_back();
+            const Node& old = nodes_[po];
+            nn[pn].first = (uint32_t)ne.size();
+            nn[pn].count = old.count;
+            for (uint32_t i = old.count; i-- > 0;) {  // edges() order; re-added in that order
+                const Edge& e = edges_[old.first + i];
+                const uint32_t cn = (uint32_t)nn.size();
+                nn.push_back(nodes_[e.target]);
+                ne.push_back(Edge{e.m, e.init_score, e.n, e.w, pn, cn});
+                stack.emplace_back(e.target, cn);
+            }
+        }
+        nodes_.swap(nn);
+        edges_.swap(ne);
+        root_ = 0;
+        if (nodes_[root_].count > 0) add_dirichlet_noise(root_);
+    }
+
+    void add_dirichlet_noise(uint32_t node_id) {  // mcts/mod.rs:419-446
+        if (params_.prior_noise_alpha == 0.0f || params_.prior_noise_epsilon == 0.0f) return;
+        const Node& nd = nodes_[node_id];
+        if (nd.count < 2) return;
+        std::vector<double> g(nd.count);
+        double sum = 0;
+        for (auto& x : g) {
+            x = rng_.gamma(params_.prior_noise_alpha);
+            sum += x;
+        }
+        if (!(sum > 0)) return;
+        const float eps = params_.prior_noise_epsilon;
+        uint32_t k = 0;
+        for (uint32_t i = nd.count; i-- > 0; k++) {  // edges() order
+            Edge& e = edges_[nd.first + i];
+            e.init_score = (1.0f - eps) * e.init_score + eps * (float)(g[k] / sum);
+        }
+    }
+
+    MctsParams params_;
+    Rng rng_;
+    std::vector<Node> nodes_;
+    std::vector<Edge> edges_;
+    uint32_t root_ = 0;
+    bool has_root_ = false;
+
+    // suspended-simulation state
+    uint32_t sims_done_ = 0, leaf_ = 0;
+    bool waiting_ = false;
+    std::vector<uint32_t> path_;
+    mutable std::vector<std::pair<uint64_t, const Position*>> seen_;
+};
+
+}  // namespace cattus

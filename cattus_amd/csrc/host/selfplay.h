@@ -1,0 +1,488 @@
+// Self-play driver: many concurrent games per evaluator, leaves batched across games.
+//
+// Restates, on the host:
+//   NNetwork::evaluate / flip / calc_moves_probs   engine/src/net/mod.rs:74-119,158-182
+//   ValueFuncCache::get_or_compute                 engine/src/mcts/cache.rs:10-76
+//   SelfPlayWorker::generate_data, write_data_entry  training/self-play/src/self_play.rs:179-275
+//   serializers                                    training/self-play/src/self_play.rs:33-61, serialize/*.rs
+//
+// Threading model.  The reference runs `threads` OS threads, each playing whole games with two
+// persistent MctsPlayers and meeting the other threads in Batcher::apply.  Here a "slot" is what a
+// reference worker thread is (two persistent players, games pulled from a shared counter), but a
+// slot is a resumable state machine: in every round each slot advances until its search needs a
+// network evaluation, the round's leaves are evaluated as one batch through the `net` callback
+// (cattus_hip_eval on the GPU), and results are handed back.  Slots advance in parallel (OpenMP).
+// Games, trees and evaluations are independent of how leaves are grouped into batches, so per-game
+// results equal those of the reference's one-thread-per-game schedule in deterministic settings.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "mcts.h"
+
+namespace cattus {
+
+// Raw network callback: planes [n][PLANES][PLANE_WORDS] -> policy [n][MOVES], value [n]; 0 = ok.
+typedef int (*net_eval_fn)(void* ctx, const uint64_t* planes, uint32_t n, float* policy, float* value);
+
+struct NetHandle {
+    net_eval_fn fn = nullptr;
+    void* ctx = nullptr;
+};
+
+struct Metrics {
+    std::atomic<uint64_t> cache_hits{0}, cache_misses{0}, activation_count{0}, node_evals{0};
+    double run_duration_ema = 0.0, search_duration_ema = 0.0;  // RunningAverage eps 0.99 (util/metric.rs)
+    std::mutex mu;
+    void set_run(double s) {
+        std::lock_guard<std::mutex> lk(mu);
+        run_duration_ema = 0.01 * run_duration_ema + 0.99 * s;
+    }
+    void set_search(double s) {
+        std::lock_guard<std::mutex> lk(mu);
+        search_duration_ema = 0.01 * search_duration_ema + 0.99 * s;
+    }
+};
+
+// ---- evaluation cache (mcts/cache.rs): key = position flipped to Player1, FIFO eviction -----------
+template <typename G>
+class EvalCache {
+   public:
+    explicit EvalCache(size_t max_size) : max_size_(max_size ? max_size : 1) {
+        per_shard_ = (max_size_ + SHARDS - 1) / SHARDS;
+    }
+    bool get(const typename G::Position& pos, Evaluation<G>& out) {
+        Shard& s = shards_[pos.hash() % SHARDS];
+        std::lock_guard<std::mutex> lk(s.mu);
+        auto range = s.map.equal_range(pos.hash());
+        for (auto it = range.first; it != range.second; ++it)
+            if (it->second.first == pos) {
+                out = it->second.second;
+                return true;
+            }
+        return false;
+    }
+    // returns false if the position was already present (the reference then returns the cached value)
+    bool insert(const typename G::Position& pos, const Evaluation<G>& ev, Evaluation<G>* existing) {
+        Shard& s = shards_[pos.hash() % SHARDS];
+        std::lock_guard<std::mutex> lk(s.mu);
+        auto range = s.map.equal_range(pos.hash());
+        for (auto it = range.first; it != range.second; ++it)
+            if (it->second.first == pos) {
+                if (existing) *existing = it->second.second;
+                return false;
+            }
+        while (s.fifo.size() >= per_shard_) {
+            const auto& old = s.fifo.front();
+            auto r = s.map.equal_range(old.hash());
+            for (auto it = r.first; it != r.second; ++it)
+                if (it->second.first == old) {
+                    s.map.erase(it);
+                    break;
+                }
+            s.fifo.pop_front();
+        }
+        s.map.emplace(pos.hash(), std::make_pair(pos, ev));
+        s.fifo.push_back(pos);
+        return true;
+    }
+
+   private:
+    static constexpr size_t SHARDS = 64;
+    struct Shard {
+        std::mutex mu;
+        std::unordered_multimap<uint64_t, std::pair<typename G::Position, Evaluation<G>>> map;
+        std::deque<typename G::Position> fifo;
+    };
+    Shard shards_[SHARDS];
+    size_t max_size_, per_shard_;
+};
+
+// ---- NNetwork::evaluate split around the network call ---------------------------------------------
+template <typename G>
+struct PendingLeaf {
+    typename G::Position pos;  // flipped so that Player1 is to move
+    bool flipped = false;
+    uint64_t planes[G::PLANES * G::PLANE_WORDS];
+};
+
+template <typename G>
+class NetValueFunction {
+   public:
+    NetValueFunction(NetHandle net, size_t cache_size, Metrics* m) : net_(net), cache_(cache_size), metrics_(m) {}
+    NetHandle net() const { return net_; }
+
+    // flip_pos_if_needed + cache probe + to_planes (net/mod.rs:79-94). true = served from the cache.
+    bool prepare(const typename G::Position& position, PendingLeaf<G>& pend, Evaluation<G>& out) {
+        pend.flipped = position.turn() != PLAYER1;
+        pend.pos = pend.flipped ? position.flipped() : position;
+        Evaluation<G> cached;
+        if (cache_.get(pend.pos, cached)) {
+            metrics_->cache_hits++;
+            unflip(cached, pend.flipped, out);
+            return true;
+        }
+        pend.pos.planes(pend.planes);
+        return false;
+    }
+    // calc_moves_probs + cache insert + flip_score_if_needed (net/mod.rs:100-119, cache.rs:49-74, net/mod.rs:166-182)
+    void finish(const PendingLeaf<G>& pend, const float* logits, float value, Evaluation<G>& out) {
+        Evaluation<G> ev;
+        std::vector<typename G::Move> moves;
+        pend.pos.legal_moves(moves);
+        softmax_legal(moves, logits, ev.probs);
+        ev.value = value;
+        Evaluation<G> existing;
+        if (cache_.insert(pend.pos, ev, &existing)) {
+            metrics_->cache_misses++;
+        } else {
+            metrics_->cache_hits++;
+            ev = existing;
+        }
+        unflip(ev, pend.flipped, out);
+    }
+
+    static void softmax_legal(const std::vector<typename G::Move>& moves, const float* logits,
+                              std::vector<std::pair<typename G::Move, float>>& out) {
+        out.clear();
+        float max_p = -3.40282347e+38f;  // fold(f32::MIN, f32::max)
+        for (auto& m : moves) {
+            const float s = logits[m.nn_idx()];
+            if (s > max_p) max_p = s;
+        }
+        float sum = 0.0f;
+        for (auto& m : moves) {
+            const float e = std::exp(logits[m.nn_idx()] - max_p);
+            out.emplace_back(m, e);
+            sum += e;
+        }
+        for (auto& mp : out) mp.second = mp.second / sum;
+    }
+
+   private:
+    static void unflip(const Evaluation<G>& in, bool flipped, Evaluation<G>& out) {
+        out = in;
+        if (!flipped) return;
+        out.value = -in.value;
+        for (auto& mp : out.probs) mp.first = mp.first.flipped();
+    }
+    NetHandle net_;
+    EvalCache<G> cache_;
+    Metrics* metrics_;
+};
+
+// ---- .traindata records (self_play.rs:33-61, serialize/{chess,hex,ttt}.rs) ------------------------
+template <typename G>
+struct Serializer {
+    static constexpr bool IS_CHESS = G::MOVES == 1880;
+    static constexpr size_t RECORD_BYTES =
+        IS_CHESS ? (size_t)G::PLANES * G::PLANE_WORDS * 8 + 235 + 225 * 4 + 1 : (size_t)G::PLANES * G::PLANE_WORDS * 8 + G::MOVES * 4 + 1;
+
+    // pos must have Player1 to move; winner +1/-1/0 from Player1's side
+    static void serialize(const typename G::Position& pos, std::vector<std::pair<typename G::Move, float>> probs,
+                          int8_t winner, uint8_t* out) {
+        uint64_t planes[G::PLANES * G::PLANE_WORDS];
+        pos.planes(planes);
+        uint8_t* p = out;
+        memcpy(p, planes, sizeof planes);  // little-endian host
+        p += sizeof planes;
+        if (IS_CHESS) {
+            // moves sorted by nn index; 235-byte bitmap + 225 packed probabilities (serialize/chess.rs:28-53)
+            std::stable_sort(probs.begin(), probs.end(),
+                             [](const auto& a, const auto& b) { return a.first.nn_idx() < b.first.nn_idx(); });
+            uint8_t bitmap[235];
+            float packed[225];
+            memset(bitmap, 0, sizeof bitmap);
+            for (auto& x : packed) x = -1.0f;
+            size_t k = 0;
+            for (auto& mp : probs) {
+                const int idx = mp.first.nn_idx();
+                bitmap[idx / 8] |= (uint8_t)(1u << (idx % 8));
+                if (k < 225) packed[k++] = mp.second;
+            }
+            memcpy(p, bitmap, 235), p += 235;
+            memcpy(p, packed, 225 * 4), p += 225 * 4;
+        } else {
+            float all[G::MOVES];
+            for (auto& x : all) x = -1.0f;  // -1 marks illegal moves (self_play.rs:40-46)
+            for (auto& mp : probs) all[mp.first.nn_idx()] = mp.second;
+            memcpy(p, all, sizeof all), p += sizeof all;
+        }
+        *p = (uint8_t)winner;
+    }
+};
+
+struct Record {
+    uint32_t game_idx, pos_idx;
+    uint8_t dir;  // 0 -> out_dir1, 1 -> out_dir2
+    std::vector<uint8_t> bytes;
+};
+
+struct SelfPlayConfig {
+    MctsParams mcts;
+    uint32_t batch_size = 1;        // model.batch_size
+    uint32_t threads = 1;           // host worker threads advancing slots
+    size_t cache_size = 1000;       // mcts.cache_size
+    uint32_t concurrent_games = 0;  // slots; 0 -> max(threads, batch_size)
+    uint64_t seed = 1;
+    // this process plays global game indices first_game + k*game_stride, k = 0..games_num-1
+    uint32_t first_game = 0, game_stride = 1;
+};
+
+struct SelfPlayResult {
+    uint32_t w1 = 0, w2 = 0, d = 0;
+    uint64_t positions = 0;
+    double seconds = 0;
+};
+
+template <typename G>
+class SelfPlayRunner {
+   public:
+    typedef typename G::Position Position;
+    typedef typename G::Move Move;
+
+    SelfPlayRunner(const SelfPlayConfig& cfg, NetHandle net1, NetHandle net2, bool same_model)
+        : cfg_(cfg), vf1_(net1, cfg.cache_size, &metrics_), vf2_(net2, cfg.cache_size, &metrics_), same_model_(same_model) {}
+
+    Metrics& metrics() { return metrics_; }
+    const std::string& error() const { return error_; }
+
+    // SelfPlayRunner::generate_data (self_play.rs:94-141). Records go to `records` (and to disk if
+    // the out dirs are non-empty).  games_num must be even (self_play.rs:100).
+    int generate_data(uint32_t games_num, const std::string& out_dir1, const std::string& out_dir2,
+                      std::vector<Record>* records, SelfPlayResult& res) {
+        if (games_num % 2 != 0) {
+            error_ = "Games num should be a multiple of 2";
+            return -1;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t nslots = cfg_.concurrent_games ? cfg_.concurrent_games : std::max(cfg_.threads, cfg_.batch_size);
+        nslots = std::max(1u, std::min(nslots, std::max(games_num, 1u)));
+        std::vector<Slot> slots;
+        slots.reserve(nslots);
+        for (uint32_t i = 0; i < nslots; i++) slots.emplace_back(cfg_.mcts, cfg_.seed * 1000003ull + i);
+        std::atomic<uint32_t> next_game{0};
+        std::mutex out_mu;
+        int rc = 0;
+        const size_t words = (size_t)G::PLANES * G::PLANE_WORDS;
+        std::vector<uint64_t> planes;
+        std::vector<float> policy, value;
+        std::vector<uint32_t> who;
+
+        for (;;) {
+            // phase 1: every slot consumes its pending result (if any) and runs until the next leaf
+#pragma omp parallel for schedule(dynamic, 1) num_threads(cfg_.threads)
+            for (int64_t si = 0; si < (int64_t)slots.size(); si++)
+                advance(slots[si], next_game, games_num, out_dir1, out_dir2, records, res, out_mu);
+
+            // phase 2: one batch per network over this round's leaves
+            bool any = false;
+            for (int netid = 0; netid < 2; netid++) {
+                who.clear();
+                for (uint32_t si = 0; si < slots.size(); si++)
+                    if (slots[si].state == Slot::WAIT_EVAL && slots[si].netid == netid) who.push_back(si);
+                if (who.empty()) continue;
+                any = true;
+                NetHandle net = netid == 0 ? vf1_.net() : vf2_.net();
+                planes.resize(who.size() * words);
+                policy.resize(who.size() * (size_t)G::MOVES);
+                value.resize(who.size());
+                for (size_t k = 0; k < who.size(); k++) memcpy(&planes[k * words], slots[who[k]].pend.planes, words * 8);
+                for (size_t off = 0; off < who.size(); off += cfg_.batch_size) {
+                    const uint32_t n = (uint32_t)std::min<size_t>(cfg_.batch_size, who.size() - off);
+                    const auto r0 = std::chrono::steady_clock::now();
+                    const int erc = net.fn(net.ctx, &planes[off * words], n, &policy[off * (size_t)G::MOVES], &value[off]);
+                    if (erc != 0) {
+                        error_ = "network evaluation failed with status " + std::to_string(erc);
+                        return erc;
+                    }
+                    metrics_.set_run(std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count());
+                    metrics_.activation_count++;  // counts batches, as the reference does (net/mod.rs:68)
+                    metrics_.node_evals += n;
+                }
+                for (size_t k = 0; k < who.size(); k++) {
+                    Slot& s = slots[who[k]];
+                    s.logits.assign(&policy[k * (size_t)G::MOVES], &policy[(k + 1) * (size_t)G::MOVES]);
+                    s.value = value[k];
+                    s.state = Slot::HAVE_RESULT;
+                }
+            }
+            if (!any) {
+                bool all_done = true;
+                for (auto& s : slots) all_done &= s.state == Slot::DONE;
+                if (all_done) break;
+            }
+        }
+        for (auto& s : slots)
+            if (!s.error.empty()) error_ = s.error, rc = -2;
+        res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    }
+
+   private:
+    struct Slot {
+        enum State { IDLE, NEXT_MOVE, SEARCHING, WAIT_EVAL, HAVE_RESULT, DONE };
+        MctsPlayer<G> p1, p2;
+        State state = IDLE;
+        int netid = 0;
+        MctsPlayer<G>* cur = nullptr;
+        uint32_t game_idx = 0;
+        bool players_switch = false;
+        std::vector<Position> history;
+        bool repetition_detected = false;
+        std::vector<std::pair<Position, std::vector<std::pair<Move, float>>>> pairs;
+        PendingLeaf<G> pend;
+        std::vector<float> logits;
+        float value = 0;
+        std::chrono::steady_clock::time_point search_t0;
+        std::string error;
+        Slot(const MctsParams& p, uint64_t seed) : p1(p, seed * 2 + 1), p2(p, seed * 2 + 2) {}
+    };
+
+    Status game_status(const Slot& s) const {  // ChessGame::status (chess/core.rs:431-436) / position status
+        if (s.repetition_detected) return Status::draw();
+        return s.history.back().status();
+    }
+    void play(Slot& s, Move m) {  // Game::play_single_turn (chess/core.rs:438-450)
+        Position np = s.history.back().moved(m);
+        if (G::REPETITION_LIMIT > 1) {
+            int cnt = 1;
+            for (auto& p : s.history)
+                if (p == np) cnt++;
+            if (cnt >= G::REPETITION_LIMIT) s.repetition_detected = true;
+        }
+        s.history.push_back(np);
+    }
+
+    void advance(Slot& s, std::atomic<uint32_t>& next_game, uint32_t games_num, const std::string& d1, const std::string& d2,
+                 std::vector<Record>* records, SelfPlayResult& res, std::mutex& out_mu) {
+        for (;;) {
+            switch (s.state) {
+                case Slot::DONE:
+                case Slot::WAIT_EVAL:
+                    return;
+                case Slot::IDLE: {
+                    const uint32_t local = next_game.fetch_add(1);
+                    if (local >= games_num) {
+                        s.state = Slot::DONE;
+                        return;
+                    }
+                    s.game_idx = cfg_.first_game + local * cfg_.game_stride;
+                    s.players_switch = s.game_idx % 2 == 1;
+                    s.history.assign(1, Position::initial());
+                    s.repetition_detected = false;
+                    s.pairs.clear();
+                    s.state = Slot::NEXT_MOVE;
+                    break;
+                }
+                case Slot::NEXT_MOVE: {
+                    const Status st = game_status(s);
+                    if (st.finished) {
+                        finish_game(s, st.winner, d1, d2, records, res, out_mu);
+                        s.state = Slot::IDLE;
+                        break;
+                    }
+                    Color player = s.history.back().turn();
+                    if (s.players_switch) player = opposite(player);
+                    s.cur = player == PLAYER1 ? &s.p1 : &s.p2;
+                    s.netid = (player == PLAYER1 || same_model_) ? 0 : 1;
+                    s.search_t0 = std::chrono::steady_clock::now();
+                    s.cur->begin_search(s.history);
+                    s.state = Slot::SEARCHING;
+                    break;
+                }
+                case Slot::HAVE_RESULT: {
+                    Evaluation<G> ev;
+                    (s.netid == 0 ? vf1_ : vf2_).finish(s.pend, s.logits.data(), s.value, ev);
+                    s.cur->deliver(ev);
+                    s.state = Slot::SEARCHING;
+                    break;
+                }
+                case Slot::SEARCHING: {
+                    const auto step = s.cur->advance(s.history);
+                    if (step == MctsPlayer<G>::NEED_EVAL) {
+                        Evaluation<G> ev;
+                        if ((s.netid == 0 ? vf1_ : vf2_).prepare(s.cur->pending_position(), s.pend, ev)) {
+                            s.cur->deliver(ev);
+                        } else {
+                            s.state = Slot::WAIT_EVAL;
+                            return;
+                        }
+                    } else {
+                        auto probs = s.cur->result();
+                        metrics_.set_search(std::chrono::duration<double>(std::chrono::steady_clock::now() - s.search_t0).count());
+                        Move m;
+                        if (!s.cur->choose_move(s.history, probs, m)) {
+                            s.error = "search returned no move";
+                            s.state = Slot::DONE;
+                            return;
+                        }
+                        s.pairs.emplace_back(s.history.back(), std::move(probs));
+                        play(s, m);
+                        s.state = Slot::NEXT_MOVE;
+                    }
+                    break;
+                }
+            }
+        }
+    }
+
+    // write_data_entry for every stored position + win counters (self_play.rs:219-241,248-275)
+    void finish_game(Slot& s, int8_t winner, const std::string& d1, const std::string& d2, std::vector<Record>* records,
+                     SelfPlayResult& res, std::mutex& out_mu) {
+        std::vector<Record> recs;
+        for (size_t pos_idx = 0; pos_idx < s.pairs.size(); pos_idx++) {
+            const Position& pos = s.pairs[pos_idx].first;
+            auto probs = s.pairs[pos_idx].second;
+            Record r;
+            r.game_idx = s.game_idx, r.pos_idx = (uint32_t)pos_idx;
+            const bool p1_turn = pos.turn() == PLAYER1;
+            r.dir = (uint8_t)((p1_turn ? 0 : 1) ^ (s.game_idx % 2));
+            int8_t w = winner;
+            Position fp = pos;
+            if (!p1_turn) {  // flip_pos_if_needed + flip_score_if_needed (self_play.rs:261-263)
+                fp = pos.flipped();
+                w = (int8_t)-w;
+                for (auto& mp : probs) mp.first = mp.first.flipped();
+            }
+            r.bytes.resize(Serializer<G>::RECORD_BYTES);
+            Serializer<G>::serialize(fp, probs, w, r.bytes.data());
+            recs.push_back(std::move(r));
+        }
+        std::lock_guard<std::mutex> lk(out_mu);
+        for (auto& r : recs) {
+            const std::string& dir = r.dir == 0 ? d1 : d2;
+            if (!dir.empty()) {
+                char name[64];
+                snprintf(name, sizeof name, "/%08u_%03u.traindata", r.game_idx, r.pos_idx);
+                FILE* f = fopen((dir + name).c_str(), "wb");
+                if (!f || fwrite(r.bytes.data(), 1, r.bytes.size(), f) != r.bytes.size()) s.error = "cannot write " + dir + name;
+                if (f) fclose(f);
+            }
+            if (records) records->push_back(std::move(r));
+        }
+        res.positions += s.pairs.size();
+        if (winner == 0) res.d++;
+        else {
+            int8_t w = winner;
+            if (s.players_switch) w = (int8_t)-w;
+            (w > 0 ? res.w1 : res.w2)++;
+        }
+    }
+
+    SelfPlayConfig cfg_;
+    Metrics metrics_;
+    NetValueFunction<G> vf1_, vf2_;
+    bool same_model_;
+    std::string error_;
+};
+
+}  // namespace cattus

@@ -1,0 +1,151 @@
+"""Self-play driver tests (host library with CPU stand-in networks; no GPU needed).
+
+Covers training/self-play/src/self_play.rs:94-275 and self_play_cmd.rs:55-153: output file names and
+directories, record contents, win counters, summary JSON, even games_num, and that results do not
+depend on threads / batch size / number of concurrent games (the reference's schedule is one game
+per thread; ours batches leaves across games)."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from cattus_amd import records
+from cattus_amd import selfplay as sp
+from cattus_amd.weights import NetDesc, hex_game, seeded_blob
+from oracle import mcts_oracle as mo
+from oracle import oracle
+
+
+def _cfg(**kw):
+    base = dict(sim_num=30, temperature_policy=[(9999, 0.0)], cache_size=1000, batch_size=1, threads=1)
+    base.update(kw)
+    return sp.make_config(**base)
+
+
+def test_games_num_must_be_even():
+    with pytest.raises(RuntimeError, match="multiple of 2"):
+        sp.run_self_play("tictactoe", _cfg(), sp.Net.stub("tictactoe"), None, 3)
+
+
+def test_output_files_records_and_counters(tmp_path):
+    d1, d2 = tmp_path / "d1", tmp_path / "d2"
+    res = sp.run_self_play("tictactoe", _cfg(), sp.Net.stub("tictactoe"), None, 4, d1, d2)
+    assert res["player1_wins"] + res["player2_wins"] + res["draws"] == 4
+    files1, files2 = sorted(os.listdir(d1)), sorted(os.listdir(d2))
+    assert len(files1) + len(files2) == res["positions"] == res["records"]
+    assert all(f.endswith(".traindata") and len(f) == len("00000000_000.traindata") for f in files1 + files2)
+    # game 0, ply 0 has Player1 to move and an even game index -> out_dir1 (self_play.rs:256-259)
+    assert "00000000_000.traindata" in files1 and "00000000_001.traindata" in files2
+    assert "00000001_000.traindata" in files2 and "00000001_001.traindata" in files1
+    # files hold exactly the in-memory records
+    for rec, (g, p, d) in zip(res["record_bytes"], res["record_meta"]):
+        path = (d1 if d == 0 else d2) / f"{g:08d}_{p:03d}.traindata"
+        assert path.read_bytes() == rec.tobytes()
+    # every record: Player1 to move, probabilities sum to 1 over legal moves, winner in {-1,0,1}
+    for rec in res["record_bytes"]:
+        e = records.parse_record("tictactoe", rec.tobytes())
+        legal = e.probs >= 0
+        assert abs(e.probs[legal].sum() - 1) < 1e-5
+        occ = int(e.planes[0, 0]) | int(e.planes[1, 0])
+        assert [bool(occ >> i & 1) for i in range(9)] == [not x for x in legal]
+        assert e.winner in (-1.0, 0.0, 1.0)
+        mine, theirs = bin(int(e.planes[0, 0])).count("1"), bin(int(e.planes[1, 0])).count("1")
+        assert theirs - mine in (0, 1)  # flipped so that the side to move owns plane 0
+
+
+def test_first_record_matches_search_trace():
+    cfg = _cfg(sim_num=40)
+    trace = sp.trace_game("hex4", cfg, sp.Net.stub("hex4"))
+    res = sp.run_self_play("hex4", cfg, sp.Net.stub("hex4"), None, 2)
+    recs = [(m, r) for m, r in zip(res["record_meta"], res["record_bytes"]) if m[0] == 0]
+    assert len(recs) == len(trace)
+    e0 = records.parse_record("hex4", recs[0][1].tobytes())
+    visits = dict(trace[0][1])
+    total = sum(visits.values())
+    for m, n in visits.items():
+        assert e0.probs[m] == np.float32(n) / np.float32(total)
+
+
+@pytest.mark.parametrize("game", ["tictactoe", "hex4"])
+def test_results_independent_of_schedule(game):
+    ref = sp.run_self_play(game, _cfg(), sp.Net.stub(game), None, 8)
+    for kw in (dict(threads=4, batch_size=4), dict(threads=3, batch_size=2, concurrent_games=8), dict(threads=2, batch_size=8, concurrent_games=5)):
+        got = sp.run_self_play(game, _cfg(**kw), sp.Net.stub(game), None, 8)
+        assert (got["record_meta"] == ref["record_meta"]).all()
+        assert (got["record_bytes"] == ref["record_bytes"]).all()
+        assert [got[k] for k in ("player1_wins", "player2_wins", "draws")] == [ref[k] for k in ("player1_wins", "player2_wins", "draws")]
+
+
+def test_game_index_sharding_matches_single_process():
+    # rank r of W plays games r, r+W, ...: the union equals the single-process run
+    whole = sp.run_self_play("tictactoe", _cfg(), sp.Net.stub("tictactoe"), None, 8)
+    parts = [sp.run_self_play("tictactoe", _cfg(first_game=r, game_stride=2), sp.Net.stub("tictactoe"), None, 4) for r in range(2)]
+    meta = np.concatenate([p["record_meta"] for p in parts])
+    recs = np.concatenate([p["record_bytes"] for p in parts])
+    order = np.lexsort((meta[:, 1], meta[:, 0]))
+    assert (meta[order] == whole["record_meta"]).all() and (recs[order] == whole["record_bytes"]).all()
+    assert sum(p["player1_wins"] for p in parts) == whole["player1_wins"]
+
+
+def test_two_models_use_separate_networks():
+    calls = {"a": 0, "b": 0}
+
+    def mk(tag, bias):
+        def net(planes):
+            calls[tag] += len(planes)
+            n = len(planes)
+            pol = np.tile(np.arange(9, dtype=np.float32) * bias, (n, 1))
+            return pol, np.zeros(n, dtype=np.float32)
+
+        return net
+
+    res = sp.run_self_play("tictactoe", _cfg(sim_num=10), sp.Net.python(mk("a", 0.1)), sp.Net.python(mk("b", -0.1)), 2)
+    assert calls["a"] > 0 and calls["b"] > 0
+    assert res["node_evals"] == calls["a"] + calls["b"]
+
+
+def test_summary_json_has_reference_metric_names(tmp_path):
+    res = sp.run_self_play("tictactoe", _cfg(), sp.Net.stub("tictactoe"), None, 2)
+    path = tmp_path / "summary.json"
+    sp.write_summary(path, res)
+    s = json.loads(path.read_text())
+    assert set(s) == {"player1_wins", "player2_wins", "draws", "metrics"}
+    for name in ("model.activation_count", "model.run_duration", "mcts.search_duration", "cache.hits", "cache.misses"):
+        assert name in s["metrics"]
+    assert s["metrics"]["cache.misses"] == res["node_evals"]
+    with pytest.raises(FileExistsError):
+        sp.write_summary(path, res)  # create_new semantics (self_play_cmd.rs:148)
+
+
+def test_temperature_and_noise_paths_run():
+    cfg = _cfg(sim_num=20, temperature_policy=[(2, 1.0), (9999, 0.0)], prior_noise_alpha=0.3, prior_noise_epsilon=0.25, seed=7)
+    a = sp.run_self_play("hex4", cfg, sp.Net.stub("hex4"), None, 2)
+    b = sp.run_self_play("hex4", cfg, sp.Net.stub("hex4"), None, 2)
+    assert (a["record_bytes"] == b["record_bytes"]).all()  # seeded, unlike the reference's thread RNG
+    assert a["positions"] > 0
+
+
+def test_config1_plumbing_run_hex4_with_oracle_network():
+    """BASELINE config 1 restated: hex4, ConvNetV1 7x16 (seeded), 100 sims/move, noise off,
+    temperature 0, batch 1, 1 thread, 2 games -- on the CPU oracle network, cross-checked against the
+    pure-Python search with the same network."""
+    d = NetDesc(**hex_game(4), blocks=7, filters=16, vhc=16, phc=16)
+    net = oracle.OracleNet(seeded_blob(d, 0))
+
+    def eval_planes(planes):
+        return net.forward(planes.reshape(len(planes), 3, 2), threads=1)
+
+    cfg = sp.make_config(sim_num=100, explore_factor=1.41421, temperature_policy=[(9999, 0.0)], cache_size=1000, batch_size=1, threads=1)
+    trace = sp.trace_game("hex4", cfg, sp.Net.python(eval_planes))
+
+    def py_net(words, moves):
+        p, v = net.forward(np.array(words, dtype=np.uint64).reshape(1, 3, 2), threads=1)
+        return p[0], v[0]
+
+    want, _ = mo.trace_game(mo.make_hex(4), 100, 1.41421, net=py_net)
+    assert trace == want
+    res = sp.run_self_play("hex4", cfg, sp.Net.python(eval_planes), None, 2)
+    assert res["player1_wins"] + res["player2_wins"] + res["draws"] == 2
+    assert len([m for m in res["record_meta"] if m[0] == 0]) == len(trace)
