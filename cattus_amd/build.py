@@ -60,7 +60,7 @@ HOST_SOURCES = [HOST_DIR / "cabi.cpp"]
 HOST_DEPS = HOST_SOURCES + [HOST_DIR / n for n in ("games.h", "chess.h", "mcts.h", "selfplay.h")] + [
     ROOT / "include" / "cattus_selfplay.h"
 ]
-HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-fvisibility=hidden", "-Wall", "-Wextra",
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fvisibility=hidden", "-Wall", "-Wextra",
               "-Wno-unused-parameter"]
 
 

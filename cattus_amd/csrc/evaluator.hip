@@ -126,6 +126,16 @@ struct PinnedBuf {
     }
 };
 
+// page-locked host ranges handed out by cattus_hip_host_alloc
+std::mutex g_pin_mu;
+std::vector<std::pair<const char*, size_t>> g_pinned;
+bool is_pinned(const void* p) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto& r : g_pinned)
+        if ((const char*)p >= r.first && (const char*)p < r.first + r.second) return true;
+    return false;
+}
+
 struct ConvLayer {
     DevBuf w, b;
     uint32_t cin = 0;  // as laid out on the device (padded for the MFMA path)
@@ -411,15 +421,24 @@ int eval_host(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy,
     HIP_TRY(hipSetDevice(e->device));
     const auto t0 = std::chrono::steady_clock::now();
     const size_t pbytes = (size_t)n * d.planes * e->cfg.plane_words * 8;
-    memcpy(e->h_planes.p, planes, pbytes);
-    HIP_TRY(hipMemcpyAsync(e->d_planes.p, e->h_planes.p, pbytes, hipMemcpyHostToDevice, e->stream));
+    // Buffers obtained from cattus_hip_host_alloc are page-locked: DMA straight from / into them.
+    // Anything else goes through the evaluator's own pinned staging buffers.
+    const bool direct = is_pinned(planes) && is_pinned(policy) && is_pinned(value);
+    const void* src_planes = planes;
+    if (!direct) {
+        memcpy(e->h_planes.p, planes, pbytes);
+        src_planes = e->h_planes.p;
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_planes.p, src_planes, pbytes, hipMemcpyHostToDevice, e->stream));
     int rc = enqueue_forward(e, e->d_planes.as<uint64_t>(), n, e->d_policy.as<float>(), e->d_value.as<float>(), e->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(e->h_policy.p, e->d_policy.p, (size_t)n * d.moves * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->h_value.p, e->d_value.p, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(direct ? (void*)policy : e->h_policy.p, e->d_policy.p, (size_t)n * d.moves * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(direct ? (void*)value : e->h_value.p, e->d_value.p, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    memcpy(policy, e->h_policy.p, (size_t)n * d.moves * 4);
-    memcpy(value, e->h_value.p, (size_t)n * 4);
+    if (!direct) {
+        memcpy(policy, e->h_policy.p, (size_t)n * d.moves * 4);
+        memcpy(value, e->h_value.p, (size_t)n * 4);
+    }
     account(e, n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return CATTUS_OK;
 }
@@ -630,6 +649,30 @@ CATTUS_API int cattus_hip_flush(cattus_eval* e) {
     }
     e->srv_cv.notify_one();
     return CATTUS_OK;
+}
+
+CATTUS_API void* cattus_hip_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        fail(CATTUS_E_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinned.emplace_back((const char*)p, bytes);
+    return p;
+}
+
+CATTUS_API void cattus_hip_host_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (auto it = g_pinned.begin(); it != g_pinned.end(); ++it)
+            if (it->first == (const char*)p) {
+                g_pinned.erase(it);
+                break;
+            }
+    }
+    (void)hipHostFree(p);
 }
 
 CATTUS_API int cattus_hip_stats(cattus_eval* e, cattus_stats* out) {

@@ -48,6 +48,8 @@ SelfPlayConfig to_config(const cattus_sp_config* c) {
     cfg.seed = c->seed;
     cfg.first_game = c->first_game;
     cfg.game_stride = std::max(1u, c->game_stride);
+    cfg.host_alloc = c->host_alloc;
+    cfg.host_free = c->host_free;
     return cfg;
 }
 

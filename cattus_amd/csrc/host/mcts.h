@@ -114,6 +114,7 @@ class MctsPlayer {
             has_root_ = true;
         }
         assert(position == nodes_[root_].pos);
+        index_history(history);
         sims_done_ = 0;
         waiting_ = false;
     }
@@ -123,7 +124,7 @@ class MctsPlayer {
         assert(!waiting_);
         while (sims_done_ < params_.sim_num) {
             select(path_);
-            const bool repetition = detect_repetition(history, path_);
+            const bool repetition = detect_repetition(path_);
             leaf_ = path_.empty() ? root_ : edges_[path_.back()].target;
             const Status st = nodes_[leaf_].status();
             if (repetition) {
@@ -263,22 +264,46 @@ class MctsPlayer {
         }
     }
 
-    bool detect_repetition(const std::vector<Position>& history, const std::vector<uint32_t>& path) const {
-        // mcts/mod.rs:133-154: count equal positions over game history + search path; limit reached -> draw
+    // mcts/mod.rs:133-154: count equal positions over game history + search path; the first position
+    // whose count reaches the limit makes the leaf a draw.  The game history is fixed during one
+    // search, so its positions are counted once (begin_search) instead of once per simulation.
+    void index_history(const std::vector<Position>& history) {
+        hist_.clear();
+        hist_limit_reached_ = false;
+        if (G::REPETITION_LIMIT <= 1) return;
+        for (const Position& p : history) {
+            const uint64_t h = p.hash();
+            bool found = false;
+            for (auto& e : hist_)
+                if (e.hash == h && *e.pos == p) {
+                    if (++e.count >= G::REPETITION_LIMIT) hist_limit_reached_ = true;
+                    found = true;
+                    break;
+                }
+            if (!found) {
+                hist_.push_back(HistEntry{h, &p, 1});
+                if (1 >= G::REPETITION_LIMIT) hist_limit_reached_ = true;
+            }
+        }
+    }
+    bool detect_repetition(const std::vector<uint32_t>& path) const {
         if (G::REPETITION_LIMIT <= 1) return false;
-        seen_.clear();
-        auto visit = [&](const Position& p) {
+        if (hist_limit_reached_) return true;
+        for (size_t i = 0; i < path.size(); i++) {
+            const Position& p = nodes_[edges_[path[i]].target].pos;
             const uint64_t h = p.hash();
             int cnt = 1;
-            for (auto& s : seen_)
-                if (s.first == h && *s.second == p) cnt++;
-            seen_.emplace_back(h, &p);
-            return cnt >= G::REPETITION_LIMIT;
-        };
-        for (auto& p : history)
-            if (visit(p)) return true;
-        for (uint32_t e : path)
-            if (visit(nodes_[edges_[e].target].pos)) return true;
+            for (const auto& e : hist_)
+                if (e.hash == h && *e.pos == p) {
+                    cnt += e.count;
+                    break;
+                }
+            for (size_t j = 0; j < i; j++) {
+                const Position& q = nodes_[edges_[path[j]].target].pos;
+                if (q.hash() == h && q == p) cnt++;
+            }
+            if (cnt >= G::REPETITION_LIMIT) return true;
+        }
         return false;
     }
 
@@ -371,7 +396,13 @@ class MctsPlayer {
     uint32_t sims_done_ = 0, leaf_ = 0;
     bool waiting_ = false;
     std::vector<uint32_t> path_;
-    mutable std::vector<std::pair<uint64_t, const Position*>> seen_;
+    struct HistEntry {
+        uint64_t hash;
+        const Position* pos;  // into the caller's history vector, which outlives the search
+        int count;
+    };
+    std::vector<HistEntry> hist_;
+    bool hist_limit_reached_ = false;
 };
 
 }  // namespace cattus

@@ -9,20 +9,22 @@
 // Threading model.  The reference runs `threads` OS threads, each playing whole games with two
 // persistent MctsPlayers and meeting the other threads in Batcher::apply.  Here a "slot" is what a
 // reference worker thread is (two persistent players, games pulled from a shared counter), but a
-// slot is a resumable state machine: in every round each slot advances until its search needs a
-// network evaluation, the round's leaves are evaluated as one batch through the `net` callback
-// (cattus_hip_eval on the GPU), and results are handed back.  Slots advance in parallel (OpenMP).
+// slot is a resumable state machine: `threads` workers advance slots until their search needs a
+// network evaluation, one evaluation thread gathers waiting leaves into batches and runs them
+// through the `net` callback (cattus_hip_eval on the GPU), and hands the results back.
 // Games, trees and evaluations are independent of how leaves are grouped into batches, so per-game
 // results equal those of the reference's one-thread-per-game schedule in deterministic settings.
 #pragma once
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -124,10 +126,9 @@ class NetValueFunction {
     bool prepare(const typename G::Position& position, PendingLeaf<G>& pend, Evaluation<G>& out) {
         pend.flipped = position.turn() != PLAYER1;
         pend.pos = pend.flipped ? position.flipped() : position;
-        Evaluation<G> cached;
-        if (cache_.get(pend.pos, cached)) {
+        if (cache_.get(pend.pos, out)) {
             metrics_->cache_hits++;
-            unflip(cached, pend.flipped, out);
+            unflip(out, pend.flipped);
             return true;
         }
         pend.pos.planes(pend.planes);
@@ -135,19 +136,13 @@ class NetValueFunction {
     }
     // calc_moves_probs + cache insert + flip_score_if_needed (net/mod.rs:100-119, cache.rs:49-74, net/mod.rs:166-182)
     void finish(const PendingLeaf<G>& pend, const float* logits, float value, Evaluation<G>& out) {
-        Evaluation<G> ev;
-        std::vector<typename G::Move> moves;
+        static thread_local std::vector<typename G::Move> moves;
         pend.pos.legal_moves(moves);
-        softmax_legal(moves, logits, ev.probs);
-        ev.value = value;
-        Evaluation<G> existing;
-        if (cache_.insert(pend.pos, ev, &existing)) {
-            metrics_->cache_misses++;
-        } else {
-            metrics_->cache_hits++;
-            ev = existing;
-        }
-        unflip(ev, pend.flipped, out);
+        softmax_legal(moves, logits, out.probs);
+        out.value = value;
+        if (cache_.insert(pend.pos, out, &out)) metrics_->cache_misses++;
+        else metrics_->cache_hits++;  // someone else inserted it meanwhile: `out` now holds the cached value
+        unflip(out, pend.flipped);
     }
 
     static void softmax_legal(const std::vector<typename G::Move>& moves, const float* logits,
@@ -168,11 +163,10 @@ class NetValueFunction {
     }
 
    private:
-    static void unflip(const Evaluation<G>& in, bool flipped, Evaluation<G>& out) {
-        out = in;
+    static void unflip(Evaluation<G>& ev, bool flipped) {
         if (!flipped) return;
-        out.value = -in.value;
-        for (auto& mp : out.probs) mp.first = mp.first.flipped();
+        ev.value = -ev.value;
+        for (auto& mp : ev.probs) mp.first = mp.first.flipped();
     }
     NetHandle net_;
     EvalCache<G> cache_;
@@ -235,6 +229,10 @@ struct SelfPlayConfig {
     uint64_t seed = 1;
     // this process plays global game indices first_game + k*game_stride, k = 0..games_num-1
     uint32_t first_game = 0, game_stride = 1;
+    // optional allocator for the batch buffers handed to the network callback (page-locked memory
+    // from cattus_hip_host_alloc lets the evaluator DMA straight into them)
+    void* (*host_alloc)(size_t) = nullptr;
+    void (*host_free)(void*) = nullptr;
 };
 
 struct SelfPlayResult {
@@ -271,60 +269,133 @@ class SelfPlayRunner {
         for (uint32_t i = 0; i < nslots; i++) slots.emplace_back(cfg_.mcts, cfg_.seed * 1000003ull + i);
         std::atomic<uint32_t> next_game{0};
         std::mutex out_mu;
-        int rc = 0;
         const size_t words = (size_t)G::PLANES * G::PLANE_WORDS;
-        std::vector<uint64_t> planes;
-        std::vector<float> policy, value;
-        std::vector<uint32_t> who;
 
-        for (;;) {
-            // phase 1: every slot consumes its pending result (if any) and runs until the next leaf
-#pragma omp parallel for schedule(dynamic, 1) num_threads(cfg_.threads)
-            for (int64_t si = 0; si < (int64_t)slots.size(); si++)
-                advance(slots[si], next_game, games_num, out_dir1, out_dir2, records, res, out_mu);
+        // Scheduler.  `ready` holds slots the host may advance, `pending[net]` slots whose search waits
+        // for a network evaluation.  Worker threads pop ready slots, consume the slot's result (if any)
+        // and run its search up to the next leaf.  The evaluation thread fires a batch as soon as
+        // batch_size leaves are pending, or -- when fewer are pending -- once no slot is being advanced
+        // any more (then every live slot is waiting, so the batch cannot grow).  While a batch is on the
+        // GPU the workers advance the other slots.  Which leaves share a batch depends on timing;
+        // per-leaf results do not, so the games do not either.
+        std::mutex mu;
+        std::condition_variable cv_work, cv_eval;
+        std::deque<uint32_t> ready;
+        std::vector<uint32_t> pending[2];
+        uint32_t busy = 0, done = 0;
+        bool finished = false;
+        int rc = 0;
+        for (uint32_t i = 0; i < nslots; i++) ready.push_back(i);
 
-            // phase 2: one batch per network over this round's leaves
-            bool any = false;
-            for (int netid = 0; netid < 2; netid++) {
-                who.clear();
-                for (uint32_t si = 0; si < slots.size(); si++)
-                    if (slots[si].state == Slot::WAIT_EVAL && slots[si].netid == netid) who.push_back(si);
-                if (who.empty()) continue;
-                any = true;
+        // ring of batch buffers: a buffer is reusable once every leaf of its batch has been consumed
+        constexpr int NBUF = 4;
+        struct BatchBuf {
+            uint64_t* planes = nullptr;
+            float *policy = nullptr, *value = nullptr;
+            uint32_t refs = 0;  // guarded by mu
+        } bufs[NBUF];
+        auto halloc = [&](size_t bytes) { return cfg_.host_alloc ? cfg_.host_alloc(bytes) : malloc(bytes); };
+        auto hfree = [&](void* p) { cfg_.host_free ? cfg_.host_free(p) : free(p); };
+        for (auto& b : bufs) {
+            b.planes = (uint64_t*)halloc(cfg_.batch_size * words * 8);
+            b.policy = (float*)halloc((size_t)cfg_.batch_size * G::MOVES * 4);
+            b.value = (float*)halloc(cfg_.batch_size * 4);
+            if (!b.planes || !b.policy || !b.value) {
+                error_ = "cannot allocate batch buffers";
+                return -4;
+            }
+        }
+
+        auto worker = [&]() {
+            constexpr size_t CHUNK = 4;  // slots taken per lock acquisition
+            uint32_t mine[CHUNK];
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv_work.wait(lk, [&] { return finished || !ready.empty(); });
+                if (finished) return;
+                size_t k = 0;
+                while (k < CHUNK && !ready.empty()) mine[k++] = ready.front(), ready.pop_front();
+                busy += (uint32_t)k;
+                lk.unlock();
+                int released[CHUNK];
+                for (size_t i = 0; i < k; i++) {
+                    Slot& sl = slots[mine[i]];
+                    released[i] = sl.state == Slot::HAVE_RESULT ? sl.batch : -1;
+                    advance(sl, next_game, games_num, out_dir1, out_dir2, records, res, out_mu);
+                }
+                lk.lock();
+                busy -= (uint32_t)k;
+                bool freed = false;
+                for (size_t i = 0; i < k; i++) {
+                    Slot& sl = slots[mine[i]];
+                    if (released[i] >= 0 && --bufs[released[i]].refs == 0) freed = true;
+                    if (sl.state == Slot::WAIT_EVAL) pending[sl.netid].push_back(mine[i]);
+                    else done++;
+                }
+                (void)freed;
+                cv_eval.notify_one();
+            }
+        };
+        std::vector<std::thread> workers;
+        for (uint32_t i = 0; i < cfg_.threads; i++) workers.emplace_back(worker);
+
+        {
+            std::vector<uint32_t> who;
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                if (done == nslots || rc != 0) break;
+                int netid = pending[0].size() >= pending[1].size() ? 0 : 1;
+                const bool full = pending[netid].size() >= cfg_.batch_size;
+                const bool drained = ready.empty() && busy == 0 && !pending[netid].empty();
+                int bi = -1;
+                for (int i = 0; i < NBUF; i++)
+                    if (bufs[i].refs == 0) bi = i;
+                if ((!full && !drained) || bi < 0) {
+                    cv_eval.wait(lk);
+                    continue;
+                }
+                BatchBuf& bb = bufs[bi];
+                const size_t n = std::min<size_t>(cfg_.batch_size, pending[netid].size());
+                who.assign(pending[netid].begin(), pending[netid].begin() + n);
+                pending[netid].erase(pending[netid].begin(), pending[netid].begin() + n);
+                bb.refs = (uint32_t)n;
+                lk.unlock();
+                for (size_t k = 0; k < n; k++) memcpy(bb.planes + k * words, slots[who[k]].pend.planes, words * 8);
                 NetHandle net = netid == 0 ? vf1_.net() : vf2_.net();
-                planes.resize(who.size() * words);
-                policy.resize(who.size() * (size_t)G::MOVES);
-                value.resize(who.size());
-                for (size_t k = 0; k < who.size(); k++) memcpy(&planes[k * words], slots[who[k]].pend.planes, words * 8);
-                for (size_t off = 0; off < who.size(); off += cfg_.batch_size) {
-                    const uint32_t n = (uint32_t)std::min<size_t>(cfg_.batch_size, who.size() - off);
-                    const auto r0 = std::chrono::steady_clock::now();
-                    const int erc = net.fn(net.ctx, &planes[off * words], n, &policy[off * (size_t)G::MOVES], &value[off]);
-                    if (erc != 0) {
-                        error_ = "network evaluation failed with status " + std::to_string(erc);
-                        return erc;
-                    }
+                const auto r0 = std::chrono::steady_clock::now();
+                const int erc = net.fn(net.ctx, bb.planes, (uint32_t)n, bb.policy, bb.value);
+                if (erc == 0) {
                     metrics_.set_run(std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count());
                     metrics_.activation_count++;  // counts batches, as the reference does (net/mod.rs:68)
                     metrics_.node_evals += n;
+                    for (size_t k = 0; k < n; k++) {
+                        Slot& sl = slots[who[k]];
+                        sl.logits = bb.policy + k * (size_t)G::MOVES;
+                        sl.value = bb.value[k];
+                        sl.batch = bi;
+                        sl.state = Slot::HAVE_RESULT;
+                    }
                 }
-                for (size_t k = 0; k < who.size(); k++) {
-                    Slot& s = slots[who[k]];
-                    s.logits.assign(&policy[k * (size_t)G::MOVES], &policy[(k + 1) * (size_t)G::MOVES]);
-                    s.value = value[k];
-                    s.state = Slot::HAVE_RESULT;
+                lk.lock();
+                if (erc != 0) {
+                    error_ = "network evaluation failed with status " + std::to_string(erc);
+                    rc = erc;
+                    break;
                 }
+                for (size_t k = 0; k < n; k++) ready.push_back(who[k]);
+                cv_work.notify_all();
             }
-            if (!any) {
-                bool all_done = true;
-                for (auto& s : slots) all_done &= s.state == Slot::DONE;
-                if (all_done) break;
-            }
+            finished = true;
+            cv_work.notify_all();
         }
+        for (auto& t : workers) t.join();
+        for (auto& b : bufs) hfree(b.planes), hfree(b.policy), hfree(b.value);
+        if (rc != 0) return rc;
+        int frc = 0;
         for (auto& s : slots)
-            if (!s.error.empty()) error_ = s.error, rc = -2;
+            if (!s.error.empty()) error_ = s.error, frc = -2;
         res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return rc;
+        return frc;
     }
 
    private:
@@ -340,7 +411,8 @@ class SelfPlayRunner {
         bool repetition_detected = false;
         std::vector<std::pair<Position, std::vector<std::pair<Move, float>>>> pairs;
         PendingLeaf<G> pend;
-        std::vector<float> logits;
+        const float* logits = nullptr;  // row of the batch buffer `batch` until consumed
+        int batch = -1;
         float value = 0;
         std::chrono::steady_clock::time_point search_t0;
         std::string error;
@@ -401,8 +473,9 @@ class SelfPlayRunner {
                 }
                 case Slot::HAVE_RESULT: {
                     Evaluation<G> ev;
-                    (s.netid == 0 ? vf1_ : vf2_).finish(s.pend, s.logits.data(), s.value, ev);
+                    (s.netid == 0 ? vf1_ : vf2_).finish(s.pend, s.logits, s.value, ev);
                     s.cur->deliver(ev);
+                    s.logits = nullptr;  // the caller releases the batch buffer reference
                     s.state = Slot::SEARCHING;
                     break;
                 }

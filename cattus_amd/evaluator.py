@@ -32,6 +32,8 @@ ABI_SYMBOLS = [
     "cattus_hip_submit",
     "cattus_hip_wait",
     "cattus_hip_flush",
+    "cattus_hip_host_alloc",
+    "cattus_hip_host_free",
     "cattus_hip_stats",
     "cattus_hip_time_tower",
     "cattus_hip_planes_to_tensor",
@@ -97,6 +99,10 @@ def load_library():
     L.cattus_hip_submit.argtypes = [vp, u64p, C.POINTER(C.c_uint64)]
     L.cattus_hip_wait.argtypes = [vp, C.c_uint64, f32p, f32p]
     L.cattus_hip_flush.argtypes = [vp]
+    L.cattus_hip_host_alloc.argtypes = [C.c_size_t]
+    L.cattus_hip_host_alloc.restype = vp
+    L.cattus_hip_host_free.argtypes = [vp]
+    L.cattus_hip_host_free.restype = None
     L.cattus_hip_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cattus_hip_time_tower.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.cattus_hip_planes_to_tensor.argtypes = [C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
@@ -105,7 +111,7 @@ def load_library():
     L.cattus_hip_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("cattus_hip_last_error", "cattus_hip_version"):
+        if fn.restype is C.c_int and name not in ("cattus_hip_last_error", "cattus_hip_version", "cattus_hip_host_alloc"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -69,6 +69,8 @@ class SpConfig(C.Structure):
         ("seed", C.c_uint64),
         ("first_game", C.c_uint32),
         ("game_stride", C.c_uint32),
+        ("host_alloc", C.c_void_p),
+        ("host_free", C.c_void_p),
     ]
 
 
@@ -92,12 +94,28 @@ class SpSummary(C.Structure):
 _lib = None
 
 
+def available_cpus() -> int:
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def load_library():
     global _lib
     if _lib is not None:
         return _lib
     if not LIB_PATH.exists():
         raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `python -m cattus_amd.build`")
+    # worker threads sleep at the end of a round instead of spinning: the evaluator's server thread and the
+    # second slot group need the cores while a batch is on the GPU
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
     L = C.CDLL(str(LIB_PATH))
     vp = C.c_void_p
     L.cattus_sp_game_info.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
@@ -162,7 +180,7 @@ def make_config(
     for i, (thr, val) in enumerate(tp):
         c.temperature_threshold[i], c.temperature_value[i] = int(thr), float(val)
     c.prior_noise_alpha, c.prior_noise_epsilon = prior_noise_alpha, prior_noise_epsilon
-    c.cache_size, c.batch_size, c.threads = cache_size, batch_size, threads
+    c.cache_size, c.batch_size, c.threads = cache_size, batch_size, max(1, min(threads, available_cpus()))
     c.concurrent_games, c.seed, c.first_game, c.game_stride = concurrent_games, seed, first_game, game_stride
     return c
 
@@ -201,7 +219,11 @@ class Net:
     def hip(evaluator) -> "Net":
         """libcattus_hip's cattus_hip_eval has exactly the callback signature; ctx = evaluator handle."""
         fn = C.cast(evaluator._lib.cattus_hip_eval, C.c_void_p).value
-        return Net(fn, evaluator._h.value, keepalive=evaluator)
+        net = Net(fn, evaluator._h.value, keepalive=evaluator)
+        # page-locked batch buffers: the evaluator then transfers without a staging copy
+        net.host_alloc = C.cast(evaluator._lib.cattus_hip_host_alloc, C.c_void_p).value
+        net.host_free = C.cast(evaluator._lib.cattus_hip_host_free, C.c_void_p).value
+        return net
 
     @staticmethod
     def python(fn) -> "Net":
@@ -250,6 +272,8 @@ def run_self_play(game: str, cfg: SpConfig, net1: Net, net2: Net | None, games_n
     for d in (out_dir1, out_dir2):
         if d is not None:
             os.makedirs(d, exist_ok=True)
+    if getattr(net1, "host_alloc", None) and (net2 is None or getattr(net2, "host_alloc", None)):
+        cfg.host_alloc, cfg.host_free = net1.host_alloc, net1.host_free
     res = C.c_void_p()
     rc = L.cattus_sp_run(
         GAMES[game], C.byref(cfg), net1.fn_addr, net1.ctx, net2.fn_addr if net2 else None, net2.ctx if net2 else None,

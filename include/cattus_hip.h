@@ -89,6 +89,11 @@ int cattus_hip_submit(cattus_eval* e, const uint64_t* planes_one, uint64_t* tick
 int cattus_hip_wait(cattus_eval* e, uint64_t ticket, float* policy, float* value);
 int cattus_hip_flush(cattus_eval* e);
 
+/* Page-locked host memory.  cattus_hip_eval transfers directly from / into buffers allocated here
+ * (no staging copy); any other host memory works too, through the evaluator's own staging buffers. */
+void* cattus_hip_host_alloc(size_t bytes);
+void cattus_hip_host_free(void* p);
+
 int cattus_hip_stats(cattus_eval* e, cattus_stats* out);
 
 /* Average device time in microseconds of one 3x3-conv tower launch over `reps` forwards of n

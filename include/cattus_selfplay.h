@@ -47,6 +47,10 @@ typedef struct cattus_sp_config {
     uint32_t concurrent_games;            /* 0 = max(threads, batch_size) */
     uint64_t seed;
     uint32_t first_game, game_stride;     /* this process plays games first_game + k*game_stride */
+    /* optional allocator for the batch buffers passed to the network callback; with
+     * cattus_hip_host_alloc / cattus_hip_host_free the evaluator DMAs straight into them */
+    void* (*host_alloc)(size_t);
+    void (*host_free)(void*);
 } cattus_sp_config;
 
 typedef struct cattus_sp_summary {

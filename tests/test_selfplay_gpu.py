@@ -1,0 +1,75 @@
+"""End-to-end GPU tests: the C++ self-play driver calling the HIP evaluator through the raw C function
+pointer, checked against the same search running on the CPU oracle network."""
+
+import json
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cattus_amd import records
+from cattus_amd import selfplay as sp
+from cattus_amd.evaluator import HipEvaluator
+from cattus_amd.weights import CHESS, NetDesc, hex_game, seeded_blob
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_visit_distributions_identical_with_hip_f32_and_oracle_network():
+    """north_star: 'move-visit distributions bit-identical under fixed seed + greedy argmax'."""
+    d = NetDesc(**hex_game(7), blocks=6, filters=64, vhc=16, phc=16)
+    blob = seeded_blob(d, 1)
+    cfg = sp.make_config(sim_num=60, temperature_policy=[(9999, 0.0)], cache_size=10000, batch_size=1, threads=1)
+    net = oracle.OracleNet(blob)
+    want = sp.trace_game("hex7", cfg, sp.Net.python(lambda pl: net.forward(pl.reshape(len(pl), 3, 2), threads=1)), max_plies=8)
+    with HipEvaluator(blob, batch_size=16, plane_words=2, dtype="f32") as ev:
+        got = sp.trace_game("hex7", cfg, sp.Net.hip(ev), max_plies=8)
+        assert got == want
+        # and whole games through the batched driver: identical records whatever the batching
+        a = sp.run_self_play("hex7", sp.make_config(sim_num=30, batch_size=16, threads=4, concurrent_games=16), sp.Net.hip(ev), None, 8)
+        b = sp.run_self_play("hex7", sp.make_config(sim_num=30, batch_size=3, threads=2, concurrent_games=5), sp.Net.hip(ev), None, 8)
+        assert (a["record_bytes"] == b["record_bytes"]).all() and (a["record_meta"] == b["record_meta"]).all()
+        assert a["node_evals"] > 0 and a["activation_count"] < a["node_evals"]  # leaves were batched
+
+
+def test_chess_self_play_on_bf16_evaluator():
+    d = NetDesc(**CHESS, blocks=2, filters=64, vhc=8, phc=8)
+    blob = seeded_blob(d, 31)
+    with HipEvaluator(blob, batch_size=8, plane_words=1, dtype="bf16") as ev:
+        cfg = sp.make_config(sim_num=16, batch_size=8, threads=4, concurrent_games=8, cache_size=100000)
+        res = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, 8)
+        again = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, 8)
+    assert res["player1_wins"] + res["player2_wins"] + res["draws"] == 8
+    assert (res["record_bytes"] == again["record_bytes"]).all()  # per-leaf results are batch-independent
+    for rec in res["record_bytes"][:50]:
+        e = records.parse_record("chess", rec.tobytes())
+        legal = e.probs >= 0
+        assert 1 <= legal.sum() <= 225 and abs(e.probs[legal].sum() - 1) < 1e-4
+        assert int(e.planes[17, 0]) == 2**64 - 1
+
+
+def test_self_player_cli_contract(tmp_path):
+    """Same flags / files as the reference's <game>_self_player (self_play_cmd.rs:15-32,135-149)."""
+    d = NetDesc(**hex_game(5), blocks=1, filters=64, vhc=4, phc=4)
+    model = tmp_path / "model.cattus"
+    model.write_bytes(seeded_blob(d, 9))
+    cfg = {
+        "model": {"inference": {"engine": "hip", "device": 0, "dtype": "f32"}, "batch_size": 8},
+        "mcts": {"sim_num": 12, "explore_factor": 1.41421, "temperature_policy": [[9999, 0.0]], "prior_noise_alpha": 0.0,
+                 "prior_noise_epsilon": 0.0, "cache_size": 1000},
+        "threads": 2,
+    }
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    cmd = [sys.executable, "-m", "cattus_amd.selfplay", "--game", "hex5", "--model1-path", str(model), "--model2-path", str(model),
+           "--games-num", "4", "--out-dir1", str(tmp_path / "o1"), "--out-dir2", str(tmp_path / "o2"),
+           "--summary-file", str(tmp_path / "summary.json"), "--config-file", str(tmp_path / "cfg.json")]
+    subprocess.check_call(cmd, cwd=str(sp._PKG.parent))
+    s = json.loads((tmp_path / "summary.json").read_text())
+    assert s["player1_wins"] + s["player2_wins"] + s["draws"] == 4
+    assert s["metrics"]["model.activation_count"] > 0 and s["metrics"]["cache.misses"] > 0
+    n = len(list((tmp_path / "o1").iterdir())) + len(list((tmp_path / "o2").iterdir()))
+    assert n > 0
+    for f in (tmp_path / "o1").iterdir():
+        assert f.stat().st_size == records.record_nbytes("hex5")
