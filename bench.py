@@ -77,6 +77,51 @@ def cpu_baseline(blob, planes, budget_s: float = 20.0):
     }
 
 
+def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 20):
+    """HBM roofline of the plane-pack kernel (reference layout, f32 NCHW): chess planes for `leaves`
+    positions (1.25 GB of output, far beyond the 256 MiB Infinity Cache), timed with events on the
+    launch stream.  Algorithmic bytes per leaf = 18*8 in + 18*64*4 out = 4752."""
+    import ctypes as C
+
+    planes = torch.randint(0, 2**62, (leaves, 18, 1), dtype=torch.int64, device=dev)
+    out = torch.empty((leaves, 18, 8, 8), dtype=torch.float32, device=dev)
+
+    def launch():
+        rc = ev_lib.cattus_hip_planes_to_tensor_device(planes.data_ptr(), leaves, 18, 1, 8, leaves, out.data_ptr(), C.c_void_p(stream.cuda_stream))
+        assert rc == 0
+
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        launch()
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    nbytes = leaves * 4752
+    # spot check against the definition
+    host = out[:4].cpu().numpy().reshape(4, 18, 64)
+    bits = planes[:4].cpu().numpy().view("uint64").reshape(4, 18)
+    for b in range(4):
+        for c in range(18):
+            want = [(int(bits[b, c]) >> i) & 1 for i in range(64)]
+            assert host[b, c].astype(int).tolist() == want
+    achieved = nbytes / (us * 1e-6) / 1e9
+    return {
+        "kernel": "planes_to_tensor_nchw_kernel",
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": 8000.0,
+        "unit": "GB/s",
+        "frac": achieved / 8000.0,
+        "traffic": None,
+        "avg_launch_us": us,
+        "leaves_per_launch": leaves,
+        "bytes_per_leaf": 4752,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +222,10 @@ def main():
                 "flop_per_launch": flop_per_launch,
             },
         }
+        if args.workload == "chess20x256":
+            from cattus_amd import evaluator as ev_mod
+
+            out["roofline_plane_pack"] = pack_roofline(torch, ev_mod.load_library(), dev, stream)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, planes)
         print(json.dumps(out), flush=True)
