@@ -93,8 +93,32 @@ void launch_pack_planes_nhwc(Act act, const uint64_t* planes, uint32_t n, uint32
                            (float*)out);
 }
 
+// 8x8 boards: one plane = 64 floats = 256 B.  A thread turns one nibble of the plane word into 4 floats
+// (one 16-byte store); 16 consecutive threads cover one plane, a wave stores 1 KiB contiguous.
+__global__ void __launch_bounds__(256) planes_to_tensor_nchw64_kernel(const uint64_t* __restrict__ planes, uint64_t n_planes,
+                                                                      uint64_t total_planes, float* __restrict__ out) {
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total_planes * 16; t += (uint64_t)gridDim.x * 256) {
+        const uint64_t pl = t >> 4;
+        const uint32_t nib = (uint32_t)(t & 15);
+        const uint32_t bits = pl < n_planes ? (uint32_t)(planes[pl] >> (nib * 4)) & 0xfu : 0u;
+        f32x4 a;
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = (bits >> i) & 1u ? 1.0f : 0.0f;
+        __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(out + t * 4));
+    }
+}
+
 void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C, uint32_t w64, uint32_t S,
                                   uint32_t batch, float* out, hipStream_t st) {
+    if (S == 8 && w64 == 1) {
+        const uint64_t total_planes = (uint64_t)batch * C;
+        uint64_t blocks = (total_planes * 16 + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        if (blocks == 0) return;
+        hipLaunchKernelGGL(planes_to_tensor_nchw64_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, planes, (uint64_t)n * C,
+                           total_planes, out);
+        return;
+    }
     const uint64_t total = (uint64_t)batch * C * S * S;
     uint64_t blocks = (total + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride beyond that
@@ -153,6 +177,26 @@ struct Mfma<float> {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
     }
 };
+
+// ---- diagnostic build only (-DCATTUS_STAMPS): per-wave cycle stamps of the v2 tower kernel ------
+#ifdef CATTUS_STAMPS
+__device__ unsigned long long g_stamps[512 * 8 * 8];
+#define STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#define STAMP_RT(i) st_[i] = __builtin_amdgcn_s_memrealtime()
+#define STAMP_ACC_BEGIN unsigned long long acc_t0_ = __builtin_amdgcn_s_memtime()
+#define STAMP_ACC_END(i) st_[i] += __builtin_amdgcn_s_memtime() - acc_t0_
+#define STAMP_FLUSH(wave)                                                          \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)                               \
+        for (int q_ = 0; q_ < 8; q_++) g_stamps[(blockIdx.x * 8 + (wave)) * 8 + q_] = st_[q_]
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_RT(i)
+#define STAMP_ACC_BEGIN
+#define STAMP_ACC_END(i)
+#define STAMP_FLUSH(wave)
+#endif
 
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
@@ -375,6 +419,9 @@ __global__ void __launch_bounds__(512, 2)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const bool is_loader = wave >= 4;
+    STAMP_DECL;
+    STAMP(0);
+    STAMP_RT(5);
 
     const int nblk = gridDim.x, ncb = cout / COUT_PER_WG;
     int logical = blockIdx.x;
@@ -435,9 +482,14 @@ __global__ void __launch_bounds__(512, 2)
         issue_w(1);
         int pending = 6;  // loads issued after the data of the upcoming step
         for (int t = 0; t < T_total; t++) {
-            if (pending == 10) wait_vm_barrier<10>();
-            else if (pending == 6) wait_vm_barrier<6>();
-            else wait_vm_barrier<0>();
+            {
+                STAMP_ACC_BEGIN;
+                if (pending == 10) wait_vm_barrier<10>();
+                else if (pending == 6) wait_vm_barrier<6>();
+                else wait_vm_barrier<0>();
+                STAMP_ACC_END(4);
+            }
+            if (t == 0) STAMP(1);
             pending = 0;
             const int ch = t / 3, g = t - ch * 3;
             if (t + 2 < T_total) {
@@ -450,6 +502,10 @@ __global__ void __launch_bounds__(512, 2)
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(2);
+        STAMP(3);
+        STAMP_RT(6);
+        STAMP_FLUSH(wave);
         return;
     }
 
@@ -491,7 +547,12 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
         for (int g = 0; g < 3; g++) {
             // all fragment reads of the previous step have returned before the loaders may reuse its slab
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            {
+                STAMP_ACC_BEGIN;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                STAMP_ACC_END(4);
+            }
+            if (ch == 0 && g == 0) STAMP(1);
             // keep the per-step activation addresses from being hoisted out of the chunk loop (72 VGPRs)
             asm volatile("" : "+v"(opaque));
             constexpr int dummy = 0;
@@ -536,44 +597,83 @@ __global__ void __launch_bounds__(512, 2)
         }
     }
 
-    // ---- epilogue (identical to v1) ----
-    const size_t board = (size_t)(b0 + wave);
+    // ---- epilogue ----
+    // The accumulators hold, per lane, 4 consecutive couts of one pixel; written straight to NHWC
+    // that is 64 8-byte stores per lane hitting 32 lines each.  Instead the wave transposes its
+    // 64 px x 64 cout tile through its own (now idle) activation LDS region as f32 [px][64 cout]
+    // (XOR-swizzled 16-byte slots), then every lane owns 8 consecutive couts of one pixel: one
+    // 16/32-byte residual load and one 16/32-byte store per lane and pixel row, whole 128-byte lines.
+    STAMP(2);
+    {
+        const size_t board = (size_t)(b0 + wave);
+        const int tile0 = V2_LDS_ACT + wave * 8192;  // px 0..31; px 32..63 live 32768 bytes further
+        // skip-connection rows in the final (pixel row, 8 couts) layout, requested before the transpose
+        T resv[8][8];
+        if (HAS_RES) {
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-        for (int pb = 0; pb < 2; pb++) {
-            const int p = pb * 32 + r;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = cout0 + cb * 32 + g * 8 + h * 4;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
-                const size_t off = (board * SLOTS + p) * (size_t)cout + co;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
-                if (HAS_RES) {
-                    T rv[4];
-                    if (sizeof(T) == 2)
-                        *reinterpret_cast<uint64_t*>(rv) = *reinterpret_cast<const uint64_t*>(res + off);
-                    else
-                        *reinterpret_cast<f32x4*>(rv) = *reinterpret_cast<const f32x4*>(res + off);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = v[i] + (float)rv[i];
+            for (int i = 0; i < 8; i++) {
+                const size_t off = (board * SLOTS + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
+                if (sizeof(T) == 2) {
+                    *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
+                } else {
+                    reinterpret_cast<f32x4*>(resv[i])[0] = reinterpret_cast<const f32x4*>(res + off)[0];
+                    reinterpret_cast<f32x4*>(resv[i])[1] = reinterpret_cast<const f32x4*>(res + off)[1];
                 }
-                T ov[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    float y = v[i] > 0.0f ? v[i] : 0.0f;
-                    if (!pvalid[pb]) y = 0.0f;
-                    ov[i] = (T)y;
-                }
-                if (sizeof(T) == 2)
-                    *reinterpret_cast<uint64_t*>(out + off) = *reinterpret_cast<uint64_t*>(ov);
-                else
-                    *reinterpret_cast<f32x4*>(out + off) = *reinterpret_cast<f32x4*>(ov);
             }
         }
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int co = cout0 + cb * 32 + g * 8 + h * 4;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
+                    const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
+                    *reinterpret_cast<f32x4*>(smem + tile0 + pb * 32768 + r * 256 + slot * 16) = v;
+                }
+        const int prow = lane >> 3, cg = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int px = i * 8 + prow, pb = px >> 5, rr = px & 31;
+            const char* rowp = smem + tile0 + pb * 32768 + rr * 256;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (rr & 7)) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (rr & 7)) << 4));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const size_t off = (board * SLOTS + px) * (size_t)cout + cout0 + cg * 8;
+            if (HAS_RES) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = v[j] + (float)resv[i][j];
+            }
+            const bool valid = px < S * S;
+            T ov[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float y = v[j] > 0.0f ? v[j] : 0.0f;
+                if (!valid) y = 0.0f;
+                ov[j] = (T)y;
+            }
+            if (sizeof(T) == 2) {
+                *reinterpret_cast<f32x4*>(out + off) = *reinterpret_cast<f32x4*>(ov);
+            } else {
+                reinterpret_cast<f32x4*>(out + off)[0] = reinterpret_cast<f32x4*>(ov)[0];
+                reinterpret_cast<f32x4*>(out + off)[1] = reinterpret_cast<f32x4*>(ov)[1];
+            }
+        }
+    }
+    STAMP(3);
+    STAMP_RT(6);
+    STAMP_FLUSH(wave);
 }
+
+#ifdef CATTUS_STAMPS
+extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(unsigned long long* out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 int g_conv_impl = 2;  // 1 = single-role kernel above, 2 = loader/consumer kernel
 void set_conv_impl(int v) { g_conv_impl = v; }

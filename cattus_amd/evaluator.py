@@ -16,8 +16,11 @@ import numpy as np
 
 from .weights import NetDesc, parse_header
 
+import os
+
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libcattus_hip.so"
+# CATTUS_HIP_LIB selects another build of the same ABI (e.g. the stamped diagnostic build)
+LIB_PATH = Path(os.environ.get("CATTUS_HIP_LIB", _PKG / "libcattus_hip.so"))
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 _DTYPES = {"f32": DTYPE_F32, "bf16": DTYPE_BF16}
