@@ -210,7 +210,7 @@ def main():
             },
             "per_gpu_value": value / world,
             "roofline": {
-                "kernel": "conv3x3_mfma_kernel",
+                "kernel": "conv3x3_mfma_v2_kernel",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": peak,
