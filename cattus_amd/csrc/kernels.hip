@@ -187,8 +187,8 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 #define STAMP_ACC_BEGIN unsigned long long acc_t0_ = __builtin_amdgcn_s_memtime()
 #define STAMP_ACC_END(i) st_[i] += __builtin_amdgcn_s_memtime() - acc_t0_
 #define STAMP_FLUSH(wave)                                                          \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)                               \
-        for (int q_ = 0; q_ < 8; q_++) g_stamps[(blockIdx.x * 8 + (wave)) * 8 + q_] = st_[q_]
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)                               \
+        for (int q_ = 0; q_ < 8; q_++) g_stamps[(blockIdx.x * 16 + (wave)) * 8 + q_] = st_[q_]
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -404,11 +404,20 @@ template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
     if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifndef CATTUS_NLOAD
+#define CATTUS_NLOAD 4  // loader waves per workgroup (4 or 8)
+#endif
+constexpr int NLOAD = CATTUS_NLOAD;
+constexpr int WPL = 24 / NLOAD;  // weight pieces per loader wave and step
+constexpr int APL = 16 / NLOAD;  // activation pieces per loader wave and half-chunk
+
 template <typename T, bool HAS_RES>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                            const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S) {
     constexpr int KC = 128 / (int)sizeof(T);
@@ -418,7 +427,7 @@ __global__ void __launch_bounds__(512, 2)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const bool is_loader = wave >= 4;
+    const bool is_loader = wave >= 4;  // waves 4 .. 4+NLOAD-1
     STAMP_DECL;
     STAMP(0);
     STAMP_RT(5);
@@ -440,11 +449,11 @@ __global__ void __launch_bounds__(512, 2)
         // ================================ loader waves ================================
         const int lw = wave - 4;
         const int prow = lane >> 3, pslot = lane & 7;
-        uint32_t off_w[6], off_a[2][4];
-        int dst_w[6], dst_a[2][4];
+        uint32_t off_w[WPL], off_a[2][APL];
+        int dst_w[WPL], dst_a[2][APL];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const int pid = lw * 6 + i;                 // 0..23: tap_i = pid/8, 8 rows each
+        for (int i = 0; i < WPL; i++) {
+            const int pid = lw * WPL + i;               // 0..23: tap_i = pid/8, 8 rows each
             const int tap_i = pid >> 3, row = (pid & 7) * 8 + prow;
             const int c = pslot ^ ((row >> 1) & 7);
             off_w[i] = ((uint32_t)(tap_i * cout + row)) * row_bytes + c * 16;
@@ -453,8 +462,8 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
         for (int g = 0; g < 2; g++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int id = g * 16 + lw * 4 + i;     // 0..31, 8 rows each of [4 boards][64 px]
+            for (int i = 0; i < APL; i++) {
+                const int id = g * 16 + lw * APL + i;   // 0..31, 8 rows each of [4 boards][64 px]
                 const int row = id * 8 + prow;
                 const int c = pslot ^ ((row >> 1) & 7);
                 off_a[g][i] = (uint32_t)row * row_bytes + c * 16;
@@ -467,25 +476,25 @@ __global__ void __launch_bounds__(512, 2)
             const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)ch * 128;
             char* dst = smem + V2_LDS_W + (t % 3) * V2_SLAB;
 #pragma unroll
-            for (int i = 0; i < 6; i++) glds16(src + off_w[i], dst + dst_w[i]);
+            for (int i = 0; i < WPL; i++) glds16(src + off_w[i], dst + dst_w[i]);
         };
         auto issue_a = [&](int ch, int g) {  // half g of activation chunk ch -> buffer ch & 1
             const char* src = abase0 + (size_t)ch * 128;
             char* dst = smem + V2_LDS_ACT + (ch & 1) * 32768;
 #pragma unroll
-            for (int i = 0; i < 4; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
+            for (int i = 0; i < APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
         };
 
         issue_a(0, 0);
         issue_a(0, 1);
         issue_w(0);
         issue_w(1);
-        int pending = 6;  // loads issued after the data of the upcoming step
+        int pending = WPL;  // loads issued after the data of the upcoming step
         for (int t = 0; t < T_total; t++) {
             {
                 STAMP_ACC_BEGIN;
-                if (pending == 10) wait_vm_barrier<10>();
-                else if (pending == 6) wait_vm_barrier<6>();
+                if (pending == WPL + APL) wait_vm_barrier<WPL + APL>();
+                else if (pending == WPL) wait_vm_barrier<WPL>();
                 else wait_vm_barrier<0>();
                 STAMP_ACC_END(4);
             }
@@ -494,11 +503,11 @@ __global__ void __launch_bounds__(512, 2)
             const int ch = t / 3, g = t - ch * 3;
             if (t + 2 < T_total) {
                 issue_w(t + 2);
-                pending += 6;
+                pending += WPL;
             }
             if (g < 2 && ch + 1 < nch) {
                 issue_a(ch + 1, g);
-                pending += 4;
+                pending += APL;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -690,7 +699,7 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
             attr_set = true;                                                                              \
         }                                                                                                 \
-        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R>), grid, dim3(512), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
                               (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S); \
     } while (0)
     if (g_conv_impl == 2) {

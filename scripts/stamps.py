@@ -21,11 +21,13 @@ planes = synth.random_chess_planes(256, 2)
 for _ in range(30):
     ev.eval(planes)  # warm clocks; the stamps of the LAST tower launch (a residual conv) remain
 L = ev_mod.load_library()
-n = 256 * 8 * 8
+n = 256 * 16 * 8
 buf = (C.c_ulonglong * n)()
 assert L.cattus_hip_debug_stamps(buf, n) == 0
-st = np.array(buf[:], dtype=np.int64).reshape(256, 8, 8)
-cons, load = st[:, :4], st[:, 4:]
+st = np.array(buf[:], dtype=np.int64).reshape(256, 16, 8)
+nload = int((st[0, 4:, 0] != 0).sum())
+cons, load = st[:, :4], st[:, 4 : 4 + nload]
+print("loader waves per workgroup:", nload)
 tot = cons[..., 3] - cons[..., 0]
 rt = (cons[..., 6] - cons[..., 5]) / 100e6  # seconds (100 MHz)
 clk = np.median(tot / np.maximum(rt, 1e-12)) / 1e9
