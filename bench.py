@@ -115,11 +115,20 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
         "peak": 8000.0,
         "unit": "GB/s",
         "frac": achieved / 8000.0,
-        "traffic": None,
+        "traffic": measured_traffic("planes_to_tensor_nchw64_kernel"),
         "avg_launch_us": us,
         "leaves_per_launch": leaves,
         "bytes_per_leaf": 4752,
     }
+
+
+def measured_traffic(kernel: str):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC pass (profiles/), or None."""
+    try:
+        with open(ROOT / "profiles" / "r01_pmc_hbm_traffic.json") as f:
+            return json.load(f)[kernel]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -216,7 +225,7 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": None,
+                "traffic": measured_traffic("conv3x3_mfma_v2_kernel") if args.workload == "chess20x256" and args.dtype == "bf16" else None,
                 "avg_launch_us": launch_us,
                 "launches_per_step": launches,
                 "flop_per_launch": flop_per_launch,
