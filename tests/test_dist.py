@@ -49,3 +49,23 @@ def test_shard_games_requires_even_share():
     assert cdist.shard_games(16, 3, 4) == (3, 4, 4)
     with pytest.raises(ValueError):
         cdist.shard_games(12, 0, 4)
+
+
+def test_multi_gpu_launcher_with_stub_network_on_gloo(tmp_path):
+    """scripts/selfplay_multi_gpu.py through torch.distributed.run, 2 ranks, CPU stand-in network."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    out = tmp_path / "summary.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "scripts" / "selfplay_multi_gpu.py"), "--game", "hex4", "--net", "stub",
+           "--games-num", "8", "--sim-num", "20", "--batch-size", "4", "--concurrent-games", "4", "--threads", "1", "--out", str(out)]
+    subprocess.check_call(cmd, cwd=str(root), timeout=300)
+    s = json.loads(out.read_text())
+    assert s["n_gpus"] == 2 and s["player1_wins"] + s["player2_wins"] + s["draws"] == 8
+    whole = sp.run_self_play("hex4", sp.make_config(sim_num=20, batch_size=4, threads=1), sp.Net.stub("hex4"), None, 8)
+    # each rank has its own evaluation cache, so node_evals differ from the one-process run; records do not
+    assert s["records_pooled"] == whole["positions"] and s["node_evals"] >= whole["node_evals"]
