@@ -219,13 +219,15 @@ def main():
             },
             "per_gpu_value": value / world,
             "roofline": {
-                "kernel": "conv3x3_mfma_v2_kernel",
+                "kernel": "tower_persistent_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": measured_traffic("conv3x3_mfma_v2_kernel") if args.workload == "chess20x256" and args.dtype == "bf16" else None,
+                "traffic": measured_traffic("tower_persistent_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel")
+                if args.workload == "chess20x256" and args.dtype == "bf16"
+                else None,
                 "avg_launch_us": launch_us,
                 "launches_per_step": launches,
                 "flop_per_launch": flop_per_launch,

@@ -201,3 +201,20 @@ def test_full_size_chess_20x256_batch_256():
     # greedy move agreement between the two dtypes (reported, loosely bounded)
     agree = (p16.argmax(1) == p32.argmax(1)).mean()
     assert agree >= 0.9, agree
+
+
+def test_persistent_tower_equals_per_layer_launches(monkeypatch):
+    """CATTUS_TOWER=persistent runs the whole tower in one launch with workgroup-to-workgroup hand-offs;
+    results must be bit-identical to the per-layer kernels in both dtypes."""
+    d = NetDesc(**CHESS, blocks=6, filters=256, vhc=8, phc=8)
+    blob = seeded_blob(d, 11)
+    planes = synth.random_chess_planes(256, 11)
+    for dtype in ("f32", "bf16"):
+        monkeypatch.delenv("CATTUS_TOWER", raising=False)
+        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype) as ev:
+            p0, v0 = ev.eval(planes)
+        monkeypatch.setenv("CATTUS_TOWER", "persistent")
+        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype) as ev:
+            for n in (256, 37, 4):
+                p1, v1 = ev.eval(planes[:n])
+                assert (p1 == p0[:n]).all() and (v1 == v0[:n]).all()
