@@ -519,6 +519,9 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     }
 
     // ================================ consumer waves ================================
+#ifdef CATTUS_CONSUMER_PRIO
+    __builtin_amdgcn_s_setprio(1);  // MFMA waves win issue arbitration against the loader wave on their SIMD
+#endif
     const int r = lane & 31, h = lane >> 5;
     int ph[2], pw[2];
     bool pvalid[2];
@@ -545,6 +548,24 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    // Epilogue operands that depend on nothing computed here are requested now, so their latency hides
+    // under the main loop: the folded-BN bias of this lane's 8 cout quads, and (2-byte activations only,
+    // for register budget) the skip-connection rows in the epilogue's (pixel row, 8 couts) layout.
+    f32x4 biasv[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
+    constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2;
+    T resv[8][8];
+    if (RES_EARLY) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const size_t off = ((size_t)(b0 + wave) * SLOTS + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
+            *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
+        }
+    }
 
     // A step is 12 fragment stages (3 taps x 4 k-slices); each stage = 2 weight + 2 activation
     // fragments feeding 4 MFMAs.  Fragments are read two stages ahead of the MFMAs that consume them
@@ -617,8 +638,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         const size_t board = (size_t)(b0 + wave);
         const int tile0 = V2_LDS_ACT + wave * 8192;  // px 0..31; px 32..63 live 32768 bytes further
         // skip-connection rows in the final (pixel row, 8 couts) layout, requested before the transpose
-        T resv[8][8];
-        if (HAS_RES) {
+        if (HAS_RES && !RES_EARLY) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const size_t off = (board * SLOTS + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
@@ -636,8 +656,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             for (int pb = 0; pb < 2; pb++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const int co = cout0 + cb * 32 + g * 8 + h * 4;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
+                    const f32x4 bv = biasv[cb][g];
                     f32x4 v;
 #pragma unroll
                     for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
@@ -665,11 +684,12 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 if (!valid) y = 0.0f;
                 ov[j] = (T)y;
             }
+            // non-temporal: the line still stays in this XCD's L2 for the next layer, but leaves early
             if (sizeof(T) == 2) {
-                *reinterpret_cast<f32x4*>(out + off) = *reinterpret_cast<f32x4*>(ov);
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(ov), reinterpret_cast<f32x4*>(out + off));
             } else {
-                reinterpret_cast<f32x4*>(out + off)[0] = reinterpret_cast<f32x4*>(ov)[0];
-                reinterpret_cast<f32x4*>(out + off)[1] = reinterpret_cast<f32x4*>(ov)[1];
+                __builtin_nontemporal_store(reinterpret_cast<f32x4*>(ov)[0], reinterpret_cast<f32x4*>(out + off));
+                __builtin_nontemporal_store(reinterpret_cast<f32x4*>(ov)[1], reinterpret_cast<f32x4*>(out + off) + 1);
             }
         }
     }
