@@ -122,6 +122,26 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
     }
 
 
+def selfplay_leg(ev_blob, d, dtype: str, local_rank: int, rank: int, world: int, games: int, sims: int):
+    """End-to-end leg: real self-play (C++ search + evaluation cache + this GPU's evaluator) with the
+    reference's self-play settings (temperature 1.0 for 30 moves, Dirichlet 0.03/0.25:
+    training/config/chess_dev.yaml:52-68,83-88).  Every rank plays its own shard of the games."""
+    from cattus_amd import selfplay as sp
+    from cattus_amd.evaluator import HipEvaluator
+
+    threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
+    slots = 512
+    with HipEvaluator(ev_blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
+        cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
+                             temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25,
+                             first_game=rank, game_stride=world, seed=1 + rank)
+        t0 = time.perf_counter()
+        res = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, games, keep_records=False)
+        dt = time.perf_counter() - t0
+    return dict(seconds=dt, games=games, node_evals=res["node_evals"], batches=res["activation_count"], positions=res["positions"],
+                threads=threads, slots=slots, sims=sims)
+
+
 def measured_traffic(kernel: str):
     """HBM-side bytes per launch from the committed rocprofv3 PMC pass (profiles/), or None."""
     try:
@@ -139,6 +159,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="chess20x256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selfplay-games", type=int, default=512, help="games per GPU of the end-to-end self-play leg (0 = skip)")
+    ap.add_argument("--selfplay-sims", type=int, default=64)
     args = ap.parse_args()
 
     import torch
@@ -191,6 +213,29 @@ def main():
     # sanity: the timed kernels produced real numbers
     assert bool(torch.isfinite(d_policy).all()) and bool(torch.isfinite(d_value).all())
 
+    # ---- secondary measurement: end-to-end self-play games/hour (same network, real search on the host) ----
+    sp_out = None
+    if args.selfplay_games > 0 and args.workload == "chess20x256":
+        leg = selfplay_leg(blob, d, args.dtype, local_rank, rank, world, args.selfplay_games, args.selfplay_sims)
+        t = torch.tensor([leg["seconds"], leg["games"], leg["node_evals"], leg["batches"], leg["positions"]], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        secs = float(tmax[0].item())
+        sp_out = {
+            "games_per_hour": float(t[1].item()) * 3600.0 / secs,
+            "node_evals_per_sec": float(t[2].item()) / secs,
+            "games": int(t[1].item()),
+            "sims_per_move": leg["sims"],
+            "plies_per_game": float(t[4].item()) / max(1.0, float(t[1].item())),
+            "batch_fill": float(t[2].item()) / max(1.0, float(t[3].item())),
+            "concurrent_games_per_gpu": leg["slots"],
+            "host_threads_per_gpu": leg["threads"],
+            "seconds": secs,
+            "settings": "temperature 1.0 for 30 moves then 0, Dirichlet noise 0.03/0.25, cache 1e6, batch 256",
+        }
+
     if rank == 0:
         value = world * batch * args.steps / elapsed
         # roofline of the dominant kernel (3x3 conv tower launch), timed live with HIP events
@@ -237,6 +282,8 @@ def main():
             from cattus_amd import evaluator as ev_mod
 
             out["roofline_plane_pack"] = pack_roofline(torch, ev_mod.load_library(), dev, stream)
+        if sp_out is not None:
+            out["selfplay"] = sp_out
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, planes)
         print(json.dumps(out), flush=True)

@@ -1144,16 +1144,19 @@ __global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P,
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.0f;
-    for (uint32_t k = 0; k < K; k += 4 * KSTEP) {
-        frag a[4], b[4];
+    // The operands come straight from L2: the loop is a chain of load round trips, so keep many loads in
+    // flight (16 stages = 32 x 16 B per lane) rather than few; the MFMA order over k is unchanged.
+    constexpr uint32_t DEPTH = 16;
+    for (uint32_t k = 0; k < K; k += DEPTH * KSTEP) {
+        frag a[DEPTH], b[DEPTH];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++)
+        for (uint32_t u = 0; u < DEPTH; u++)
             if (k + u * KSTEP < K) {
                 a[u] = *reinterpret_cast<const frag*>(pp + k + u * KSTEP);
                 b[u] = *reinterpret_cast<const frag*>(qp + k + u * KSTEP);
             }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++)
+        for (uint32_t u = 0; u < DEPTH; u++)
             if (k + u * KSTEP < K) Mfma<T>::mac(a[u], b[u], acc);
     }
     const uint32_t j = j0 + r;
