@@ -130,7 +130,7 @@ def selfplay_leg(ev_blob, d, dtype: str, local_rank: int, rank: int, world: int,
     from cattus_amd.evaluator import HipEvaluator
 
     threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
-    slots = 512
+    slots = 1024  # >= 4 batches of leaves in flight keeps the batches full while other slots search
     with HipEvaluator(ev_blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
         cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
                              temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25,
@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="chess20x256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--selfplay-games", type=int, default=512, help="games per GPU of the end-to-end self-play leg (0 = skip)")
+    ap.add_argument("--selfplay-games", type=int, default=1024, help="games per GPU of the end-to-end self-play leg (0 = skip)")
     ap.add_argument("--selfplay-sims", type=int, default=64)
     args = ap.parse_args()
 
