@@ -14,6 +14,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <atomic>
+
 namespace cattus {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -993,19 +995,25 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persi
     }
 }
 
+// The opt-in for > 64 KiB of dynamic LDS is a per-device function attribute: set it once per device.
+static bool first_use_on_device(std::atomic<uint64_t>& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    return (mask.fetch_or(bit) & bit) == 0;
+}
+
 void launch_tower_persistent(Act act, const TowerArgs& args, uint32_t bpad, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const dim3 grid((bpad / BOARDS_PER_WG) * (args.cout / COUT_PER_WG)), block(256 + 64 * NLOAD);
-    static bool attr_bf16 = false, attr_f32 = false;
+    static std::atomic<uint64_t> attr_bf16{0}, attr_f32{0};
     if (act == Act::BF16) {
-        if (!attr_bf16) {
+        if (first_use_on_device(attr_bf16)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_persistent_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);
-            attr_bf16 = true;
         }
         hipExtLaunchKernelGGL((tower_persistent_kernel<__bf16>), grid, block, V2_LDS_TOTAL, st, ev_start, ev_stop, 0, args);
     } else {
-        if (!attr_f32) {
+        if (first_use_on_device(attr_f32)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_persistent_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);
-            attr_f32 = true;
         }
         hipExtLaunchKernelGGL((tower_persistent_kernel<float>), grid, block, V2_LDS_TOTAL, st, ev_start, ev_stop, 0, args);
     }
@@ -1026,11 +1034,10 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
     const dim3 grid((bpad / BOARDS_PER_WG) * (cout / COUT_PER_WG)), block(256);
 #define CATTUS_LAUNCH_CONV2(T, R)                                                                         \
     do {                                                                                                  \
-        static bool attr_set = false;                                                                     \
-        if (!attr_set) {                                                                                  \
+        static std::atomic<uint64_t> attr_set{0};                                                         \
+        if (first_use_on_device(attr_set)) {                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R>),      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
-            attr_set = true;                                                                              \
         }                                                                                                 \
         hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
                               (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S); \
@@ -1048,11 +1055,10 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 #undef CATTUS_LAUNCH_CONV2
 #define CATTUS_LAUNCH_CONV(T, R)                                                                          \
     do {                                                                                                  \
-        static bool attr_set = false;                                                                     \
-        if (!attr_set) {                                                                                  \
+        static std::atomic<uint64_t> attr_set{0};                                                         \
+        if (first_use_on_device(attr_set)) {                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<T, R>),         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);             \
-            attr_set = true;                                                                              \
         }                                                                                                 \
         hipExtLaunchKernelGGL((conv3x3_mfma_kernel<T, R>), grid, block, LDS_TOTAL, st, ev_start, ev_stop, 0, (const T*)in, \
                               (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S);    \
