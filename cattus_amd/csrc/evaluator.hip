@@ -152,6 +152,22 @@ struct ServerBatch {
     std::vector<float> policy, value;
 };
 
+constexpr int NLANES = 2;
+
+struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf d_planes, x0, a, t, y, hv, h1, d_policy, d_value;
+    DevBuf d_legal_idx, d_legal_cnt, d_probs;  // legal-move softmax operands, allocated on first use
+    uint32_t legal_stride = 0;
+    PinnedBuf h_planes, h_policy, h_value;
+    DevBuf tower_counters, tower_err;  // persistent tower: hand-off counters, time-out flag
+    PinnedBuf h_tower_err;
+    std::mutex mu;  // held while a batch uses the lane
+    ~Lane() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
 }  // namespace
 
 struct cattus_eval {
@@ -161,7 +177,6 @@ struct cattus_eval {
     Act act = Act::F32;
     uint32_t hw = 0, bpad = 0, cpad0 = 0;
     int device = 0;
-    hipStream_t stream = nullptr;
 
     ConvLayer stem;
     std::vector<std::unique_ptr<ConvLayer>> c1, c2;
@@ -170,16 +185,16 @@ struct cattus_eval {
     DevBuf head_w, head_b, w1t, b1, w2, b2, wpt, bp;
     uint32_t kvp = 0, kpp = 0;  // padded K of the value / policy FC (tuned path)
 
-    DevBuf d_planes, x0, a, t, y, hv, h1, d_policy, d_value;
-    PinnedBuf h_planes, h_policy, h_value;
+    // Two lanes = two independent sets of activation buffers, each with its own stream, so that two
+    // host threads can have a batch in flight each: one lane's transfers, launch latency and completion
+    // wake-up hide behind the other lane's kernels.  The weights are shared.
+    Lane lanes[NLANES];
+    std::atomic<unsigned> lane_rr{0};
 
-    // persistent tower (one launch for all 3x3 layers): layer table, hand-off counters, time-out flag
-    bool persistent = false;
-    DevBuf tower_layers, tower_counters, tower_err;
-    PinnedBuf h_tower_err;
+    // persistent tower (one launch for all 3x3 layers): layer table (shared), per-lane counters/flags
+    std::atomic<bool> persistent{false};
+    DevBuf tower_layers;
     uint32_t tower_out_buf = 1;  // index (1..3) of the buffer holding the tower output
-
-    std::mutex run_mu;  // serialises use of the activation buffers / stream
     std::mutex stat_mu;
     cattus_stats stats{};
 
@@ -199,7 +214,6 @@ struct cattus_eval {
         srv_cv.notify_all();
         done_cv.notify_all();
         if (server.joinable()) server.join();
-        if (stream) (void)hipStreamDestroy(stream);
     }
 };
 
@@ -324,16 +338,7 @@ int build(cattus_eval* e, const float* p) {
     const size_t bp_ = e->bpad, B = e->cfg.max_batch;
     const size_t esz = e->tuned ? (size_t)act_bytes(e->act) : 4;
     const size_t slots = e->tuned ? SLOTS : hw;
-    if ((rc = e->d_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
-    if ((rc = e->x0.alloc(bp_ * slots * e->cpad0 * esz))) return rc;
-    if ((rc = e->a.alloc(bp_ * slots * F * esz))) return rc;
-    if ((rc = e->t.alloc(bp_ * slots * F * esz))) return rc;
-    if ((rc = e->y.alloc(bp_ * slots * F * esz))) return rc;
-    if ((rc = e->hv.alloc(bp_ * (e->kvp + e->kpp) * esz))) return rc;
-    HIP_TRY(hipMemset(e->hv.p, 0, bp_ * (e->kvp + e->kpp) * esz));  // pad columns must read as zero
-    if ((rc = e->h1.alloc(bp_ * FC_HIDDEN * 4))) return rc;
-    if ((rc = e->d_policy.alloc(B * d.moves * 4))) return rc;
-    if ((rc = e->d_value.alloc(B * 4))) return rc;
+    size_t nlayers = 0;
     if (e->tuned) {
         std::vector<TowerLayer> tl;
         int cur = 1;  // buffers: 0 = x0, 1 = a, 2 = t, 3 = y
@@ -345,22 +350,38 @@ int build(cattus_eval* e, const float* p) {
             cur = nxt;
         }
         e->tower_out_buf = (uint32_t)cur;
+        nlayers = tl.size();
         if ((rc = e->tower_layers.upload(tl.data(), tl.size() * sizeof(TowerLayer)))) return rc;
-        const size_t ncnt = ((size_t)(bp_ / BOARDS_PER_WG) * tl.size() + 3) / 4 * 4;
-        if ((rc = e->tower_counters.alloc(ncnt * 4))) return rc;
-        if ((rc = e->tower_err.alloc(16))) return rc;
-        HIP_TRY(hipMemset(e->tower_err.p, 0, 16));
-        if ((rc = e->h_tower_err.alloc(16))) return rc;
-        *e->h_tower_err.as<unsigned>() = 0;
         // Default: one launch per layer.  CATTUS_TOWER=persistent selects the single-launch tower with
         // in-kernel hand-offs between the workgroups of a board group (measured +2 % on chess 20x256 at
         // batch 256; it needs those workgroups resident together and falls back on a time-out).
         const char* mode = getenv("CATTUS_TOWER");
         e->persistent = mode && strcmp(mode, "persistent") == 0;
     }
-    if ((rc = e->h_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
-    if ((rc = e->h_policy.alloc(B * d.moves * 4))) return rc;
-    if ((rc = e->h_value.alloc(B * 4))) return rc;
+    for (Lane& L : e->lanes) {
+        HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        if ((rc = L.d_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
+        if ((rc = L.x0.alloc(bp_ * slots * e->cpad0 * esz))) return rc;
+        if ((rc = L.a.alloc(bp_ * slots * F * esz))) return rc;
+        if ((rc = L.t.alloc(bp_ * slots * F * esz))) return rc;
+        if ((rc = L.y.alloc(bp_ * slots * F * esz))) return rc;
+        if ((rc = L.hv.alloc(bp_ * (e->kvp + e->kpp) * esz))) return rc;
+        HIP_TRY(hipMemset(L.hv.p, 0, bp_ * (e->kvp + e->kpp) * esz));  // pad columns must read as zero
+        if ((rc = L.h1.alloc(bp_ * FC_HIDDEN * 4))) return rc;
+        if ((rc = L.d_policy.alloc(B * d.moves * 4))) return rc;
+        if ((rc = L.d_value.alloc(B * 4))) return rc;
+        if (e->tuned) {
+            const size_t ncnt = ((size_t)(bp_ / BOARDS_PER_WG) * nlayers + 3) / 4 * 4;
+            if ((rc = L.tower_counters.alloc(ncnt * 4))) return rc;
+            if ((rc = L.tower_err.alloc(16))) return rc;
+            HIP_TRY(hipMemset(L.tower_err.p, 0, 16));
+            if ((rc = L.h_tower_err.alloc(16))) return rc;
+            *L.h_tower_err.as<unsigned>() = 0;
+        }
+        if ((rc = L.h_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
+        if ((rc = L.h_policy.alloc(B * d.moves * 4))) return rc;
+        if ((rc = L.h_value.alloc(B * 4))) return rc;
+    }
     return CATTUS_OK;
 }
 
@@ -371,7 +392,7 @@ struct TowerTimer {
 
 // Enqueue the whole forward for n leaves whose planes are at d_planes; logits/values go to
 // d_policy/d_value.  With `tt`, a HIP event pair brackets every tower conv launch.
-int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float* d_policy, float* d_value,
+int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t n, float* d_policy, float* d_value,
                     hipStream_t st, TowerTimer* tt = nullptr) {
     const cattus_net_desc& d = e->d;
     const uint32_t F = d.filters, hw = e->hw, S = d.board, w64 = e->cfg.plane_words;
@@ -381,21 +402,21 @@ int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float*
         (void)stop;
         return tt->ev[tt->used++];
     };
-    void *a = e->a.p, *t = e->t.p, *y = e->y.p;
+    void *a = L.a.p, *t = L.t.p, *y = L.y.p;
     uint32_t nb = n;
     if (e->tuned) {
         nb = (n + BOARDS_PER_WG - 1) / BOARDS_PER_WG * BOARDS_PER_WG;
-        launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, e->x0.p, st);
+        launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
         if (e->persistent) {
             // one launch for the whole tower; hand-off counters are re-zeroed by a memset node in front of it
             const uint32_t nlayers = 1 + 2 * d.blocks;
             const size_t ncnt = ((size_t)(nb / BOARDS_PER_WG) * nlayers + 3) / 4 * 4;
-            (void)hipMemsetAsync(e->tower_counters.p, 0, ncnt * 4, st);
+            (void)hipMemsetAsync(L.tower_counters.p, 0, ncnt * 4, st);
             TowerArgs ta{};
-            ta.buf[0] = e->x0.p, ta.buf[1] = e->a.p, ta.buf[2] = e->t.p, ta.buf[3] = e->y.p;
+            ta.buf[0] = L.x0.p, ta.buf[1] = L.a.p, ta.buf[2] = L.t.p, ta.buf[3] = L.y.p;
             ta.layers = e->tower_layers.as<TowerLayer>();
-            ta.counters = e->tower_counters.as<unsigned>();
-            ta.err = e->tower_err.as<unsigned>();
+            ta.counters = L.tower_counters.as<unsigned>();
+            ta.err = L.tower_err.as<unsigned>();
             ta.nlayers = (int)nlayers, ta.cout = (int)F, ta.S = (int)S;
             ta.spin_budget_ticks = 2000000;  // 20 ms
             hipEvent_t s0 = ev(false), s1 = ev(true);
@@ -403,7 +424,7 @@ int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float*
             a = ta.buf[e->tower_out_buf];
         } else {
             hipEvent_t s0 = ev(false), s1 = ev(true);
-            launch_conv3x3_mfma(e->act, e->x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, F, S, st, s0, s1);
+            launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, F, S, st, s0, s1);
             for (uint32_t i = 0; i < d.blocks; i++) {
                 s0 = ev(false), s1 = ev(true);
                 launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, F, F, S, st, s0, s1);
@@ -413,9 +434,9 @@ int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float*
             }
         }
     } else {
-        launch_planes_to_tensor_nchw(d_planes, n, d.planes, w64, S, n, e->x0.as<float>(), st);
+        launch_planes_to_tensor_nchw(d_planes, n, d.planes, w64, S, n, L.x0.as<float>(), st);
         hipEvent_t s0 = ev(false), s1 = ev(true);
-        launch_conv3x3_generic(e->x0.as<float>(), e->stem.w.as<float>(), e->stem.b.as<float>(), nullptr, (float*)a, n,
+        launch_conv3x3_generic(L.x0.as<float>(), e->stem.w.as<float>(), e->stem.b.as<float>(), nullptr, (float*)a, n,
                                d.planes, F, S, st, s0, s1);
         for (uint32_t i = 0; i < d.blocks; i++) {
             s0 = ev(false), s1 = ev(true);
@@ -430,19 +451,19 @@ int enqueue_forward(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float*
     const uint32_t kv = d.vhc * hw, kp = d.phc * hw;
     if (e->tuned) {
         HeadsMfma hd{};
-        hd.conv_w = e->head_w.p, hd.conv_b = e->head_b.as<float>(), hd.hv = e->hv.p;
-        hd.w1 = e->w1t.p, hd.b1 = e->b1.as<float>(), hd.h1 = e->h1.as<float>();
+        hd.conv_w = e->head_w.p, hd.conv_b = e->head_b.as<float>(), hd.hv = L.hv.p;
+        hd.w1 = e->w1t.p, hd.b1 = e->b1.as<float>(), hd.h1 = L.h1.as<float>();
         hd.wp = e->wpt.p, hd.bp = e->bp.as<float>(), hd.policy = d_policy;
         hd.hw = hw, hd.vhc = d.vhc, hd.phc = d.phc, hd.kvp = e->kvp, hd.kpp = e->kpp, hd.M = d.moves;
         launch_heads_mfma(e->act, a, n, F, hd, st);
-        launch_value_fc2_tanh(e->h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
+        launch_value_fc2_tanh(L.h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
     } else {
         TowerView tv;
         tv.x = a, tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;
-        launch_head_conv1x1(tv, e->head_w.as<float>(), e->head_b.as<float>(), n, F, d.vhc + d.phc, hw, e->hv.as<float>(), st);
-        launch_value_fc1(e->hv.as<float>(), kv + kp, e->w1t.as<float>(), e->b1.as<float>(), n, kv, e->h1.as<float>(), st);
-        launch_value_fc2_tanh(e->h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
-        launch_policy_fc(e->hv.as<float>(), kv + kp, kv, e->wpt.as<float>(), e->bp.as<float>(), n, kp, d.moves, d_policy, st);
+        launch_head_conv1x1(tv, e->head_w.as<float>(), e->head_b.as<float>(), n, F, d.vhc + d.phc, hw, L.hv.as<float>(), st);
+        launch_value_fc1(L.hv.as<float>(), kv + kp, e->w1t.as<float>(), e->b1.as<float>(), n, kv, L.h1.as<float>(), st);
+        launch_value_fc2_tanh(L.h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
+        launch_policy_fc(L.hv.as<float>(), kv + kp, kv, e->wpt.as<float>(), e->bp.as<float>(), n, kp, d.moves, d_policy, st);
     }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(CATTUS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(err));
@@ -461,43 +482,85 @@ void account(cattus_eval* e, uint32_t n, double seconds) {
     if (n == e->cfg.max_batch) s.full_batches += 1;
 }
 
-// Blocking host-buffer evaluation; caller holds no lock.
-int eval_host(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy, float* value) {
+struct LegalArgs {
+    const uint16_t* idx;  // [n][stride] policy indices of the legal moves
+    const uint16_t* cnt;  // [n]
+    uint32_t stride;
+    float* probs;  // [n][stride]
+};
+
+// Blocking host-buffer evaluation; caller holds no lock.  With `lg` the logits stay on the device and
+// the per-leaf softmax over the legal moves comes back instead (policy is not written).
+int eval_host(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy, float* value, const LegalArgs* lg = nullptr) {
     const cattus_net_desc& d = e->d;
-    std::lock_guard<std::mutex> lk(e->run_mu);
+    // a free lane if there is one, else queue on one of them in turn
+    std::unique_lock<std::mutex> lk;
+    Lane* lane = nullptr;
+    for (Lane& cand : e->lanes) {
+        std::unique_lock<std::mutex> tl(cand.mu, std::try_to_lock);
+        if (tl.owns_lock()) {
+            lane = &cand, lk = std::move(tl);
+            break;
+        }
+    }
+    if (!lane) {
+        lane = &e->lanes[e->lane_rr.fetch_add(1) % NLANES];
+        lk = std::unique_lock<std::mutex>(lane->mu);
+    }
+    Lane& L = *lane;
     HIP_TRY(hipSetDevice(e->device));
     const auto t0 = std::chrono::steady_clock::now();
     const size_t pbytes = (size_t)n * d.planes * e->cfg.plane_words * 8;
     // Buffers obtained from cattus_hip_host_alloc are page-locked: DMA straight from / into them.
     // Anything else goes through the evaluator's own pinned staging buffers.
-    const bool direct = is_pinned(planes) && is_pinned(policy) && is_pinned(value);
+    const bool direct = is_pinned(planes) && (lg || is_pinned(policy)) && is_pinned(value);
+    if (lg && (L.legal_stride < lg->stride || !L.d_probs.p)) {
+        const size_t B = e->cfg.max_batch;
+        int arc;
+        if ((arc = L.d_legal_idx.alloc(B * lg->stride * 2)) || (arc = L.d_legal_cnt.alloc(B * 2)) ||
+            (arc = L.d_probs.alloc(B * lg->stride * 4)))
+            return arc;
+        L.legal_stride = lg->stride;
+    }
     const void* src_planes = planes;
     if (!direct) {
-        memcpy(e->h_planes.p, planes, pbytes);
-        src_planes = e->h_planes.p;
+        memcpy(L.h_planes.p, planes, pbytes);
+        src_planes = L.h_planes.p;
     }
-    HIP_TRY(hipMemcpyAsync(e->d_planes.p, src_planes, pbytes, hipMemcpyHostToDevice, e->stream));
-    int rc = enqueue_forward(e, e->d_planes.as<uint64_t>(), n, e->d_policy.as<float>(), e->d_value.as<float>(), e->stream);
+    HIP_TRY(hipMemcpyAsync(L.d_planes.p, src_planes, pbytes, hipMemcpyHostToDevice, L.stream));
+    int rc = enqueue_forward(e, L, L.d_planes.as<uint64_t>(), n, L.d_policy.as<float>(), L.d_value.as<float>(), L.stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(direct ? (void*)policy : e->h_policy.p, e->d_policy.p, (size_t)n * d.moves * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(direct ? (void*)value : e->h_value.p, e->d_value.p, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    auto copy_out = [&]() -> int {
+        if (lg) {
+            HIP_TRY(hipMemcpyAsync(L.d_legal_idx.p, lg->idx, (size_t)n * lg->stride * 2, hipMemcpyHostToDevice, L.stream));
+            HIP_TRY(hipMemcpyAsync(L.d_legal_cnt.p, lg->cnt, (size_t)n * 2, hipMemcpyHostToDevice, L.stream));
+            if (launch_legal_softmax(L.d_policy.as<float>(), d.moves, L.d_legal_idx.as<uint16_t>(), L.d_legal_cnt.as<uint16_t>(),
+                                     lg->stride, n, L.d_probs.as<float>(), L.stream))
+                return fail(CATTUS_E_INVALID, "legal stride %u exceeds 1024", lg->stride);
+            HIP_TRY(hipMemcpyAsync(lg->probs, L.d_probs.p, (size_t)n * lg->stride * 4, hipMemcpyDeviceToHost, L.stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(direct ? (void*)policy : L.h_policy.p, L.d_policy.p, (size_t)n * d.moves * 4, hipMemcpyDeviceToHost, L.stream));
+        }
+        HIP_TRY(hipMemcpyAsync(direct ? (void*)value : L.h_value.p, L.d_value.p, (size_t)n * 4, hipMemcpyDeviceToHost, L.stream));
+        return CATTUS_OK;
+    };
+    if ((rc = copy_out())) return rc;
     if (e->persistent)
-        HIP_TRY(hipMemcpyAsync(e->h_tower_err.p, e->tower_err.p, 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->persistent && *e->h_tower_err.as<unsigned>() != 0) {
+        HIP_TRY(hipMemcpyAsync(L.h_tower_err.p, L.tower_err.p, 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    if (e->persistent && *L.h_tower_err.as<unsigned>() != 0) {
         // a hand-off wait timed out (workgroups of one board group were not resident together): the result
         // of this pass is not trustworthy.  Fall back to one launch per layer, for good.
         e->persistent = false;
         fprintf(stderr, "cattus_hip: persistent tower timed out; using per-layer launches from now on\n");
-        rc = enqueue_forward(e, e->d_planes.as<uint64_t>(), n, e->d_policy.as<float>(), e->d_value.as<float>(), e->stream);
+        rc = enqueue_forward(e, L, L.d_planes.as<uint64_t>(), n, L.d_policy.as<float>(), L.d_value.as<float>(), L.stream);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(direct ? (void*)policy : e->h_policy.p, e->d_policy.p, (size_t)n * d.moves * 4, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipMemcpyAsync(direct ? (void*)value : e->h_value.p, e->d_value.p, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        if ((rc = copy_out())) return rc;
+        HIP_TRY(hipStreamSynchronize(L.stream));
     }
     if (!direct) {
-        memcpy(policy, e->h_policy.p, (size_t)n * d.moves * 4);
-        memcpy(value, e->h_value.p, (size_t)n * 4);
+        if (!lg) memcpy(policy, L.h_policy.p, (size_t)n * d.moves * 4);
+        memcpy(value, L.h_value.p, (size_t)n * 4);
     }
     account(e, n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return CATTUS_OK;
@@ -601,7 +664,6 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if (!e->tuned && e->act == Act::BF16)
         return fail(CATTUS_E_UNSUPPORTED, "bf16 tower needs filters %% 64 == 0 and board <= 8 (got %u filters, board %u)", d.filters, d.board);
     e->bpad = (cfg->max_batch + BOARDS_PER_WG - 1) / BOARDS_PER_WG * BOARDS_PER_WG;
-    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     int rc = build(e.get(), reinterpret_cast<const float*>((const char*)weights + HEADER_BYTES));
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -629,21 +691,37 @@ CATTUS_API int cattus_hip_eval(cattus_eval* e, const uint64_t* planes, uint32_t 
     return eval_host(e, planes, n, policy, value);
 }
 
+CATTUS_API int cattus_hip_eval_legal(cattus_eval* e, const uint64_t* planes, uint32_t n, const uint16_t* legal_idx,
+                                     const uint16_t* legal_count, uint32_t legal_stride, float* probs, float* value) {
+    if (!e || !planes || !legal_idx || !legal_count || !probs || !value) return fail(CATTUS_E_INVALID, "NULL argument");
+    if (n < 1 || n > e->cfg.max_batch) return fail(CATTUS_E_INVALID, "invalid sample len %u, 1..=%u", n, e->cfg.max_batch);
+    if (legal_stride < 1 || legal_stride > 1024) return fail(CATTUS_E_INVALID, "legal_stride %u outside 1..=1024", legal_stride);
+    for (uint32_t i = 0; i < n; i++) {
+        if (legal_count[i] > legal_stride) return fail(CATTUS_E_INVALID, "leaf %u: %u legal moves > stride %u", i, legal_count[i], legal_stride);
+        for (uint32_t k = 0; k < legal_count[i]; k++)
+            if (legal_idx[(size_t)i * legal_stride + k] >= e->d.moves)
+                return fail(CATTUS_E_INVALID, "leaf %u: policy index %u >= %u", i, legal_idx[(size_t)i * legal_stride + k], e->d.moves);
+    }
+    const LegalArgs lg{legal_idx, legal_count, legal_stride, probs};
+    return eval_host(e, planes, n, nullptr, value, &lg);
+}
+
 CATTUS_API int cattus_hip_eval_device(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float* d_policy, float* d_value,
                                       void* stream) {
     if (!e || !d_planes || !d_policy || !d_value) return fail(CATTUS_E_INVALID, "NULL argument");
     if (n < 1 || n > e->cfg.max_batch) return fail(CATTUS_E_INVALID, "invalid sample len %u, 1..=%u", n, e->cfg.max_batch);
-    std::lock_guard<std::mutex> lk(e->run_mu);
+    Lane& L = e->lanes[0];
+    std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    if (e->persistent && *e->h_tower_err.as<unsigned>() != 0) {
+    hipStream_t st = stream ? (hipStream_t)stream : L.stream;
+    if (e->persistent && *L.h_tower_err.as<unsigned>() != 0) {
         // reported by an earlier asynchronous pass (copied back below): stop using the persistent tower
         e->persistent = false;
         fprintf(stderr, "cattus_hip: persistent tower timed out; using per-layer launches from now on\n");
     }
-    int rc = enqueue_forward(e, d_planes, n, d_policy, d_value, st);
+    int rc = enqueue_forward(e, L, d_planes, n, d_policy, d_value, st);
     if (rc) return rc;
-    if (e->persistent) HIP_TRY(hipMemcpyAsync(e->h_tower_err.p, e->tower_err.p, 4, hipMemcpyDeviceToHost, st));
+    if (e->persistent) HIP_TRY(hipMemcpyAsync(L.h_tower_err.p, L.tower_err.p, 4, hipMemcpyDeviceToHost, st));
     std::lock_guard<std::mutex> sl(e->stat_mu);
     e->stats.batches += 1;
     e->stats.positions += n;
@@ -751,20 +829,21 @@ CATTUS_API int cattus_hip_stats(cattus_eval* e, cattus_stats* out) {
 CATTUS_API int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, float* avg_launch_us, uint32_t* launches) {
     if (!e || !avg_launch_us || !launches) return fail(CATTUS_E_INVALID, "NULL argument");
     if (n < 1 || n > e->cfg.max_batch || reps < 1) return fail(CATTUS_E_INVALID, "bad n/reps");
-    std::lock_guard<std::mutex> lk(e->run_mu);
+    Lane& L = e->lanes[0];
+    std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
     const uint32_t per_fwd = (e->tuned && e->persistent) ? 1 : 1 + 2 * e->d.blocks;
     TowerTimer tt;
     tt.ev.resize((size_t)2 * per_fwd);
     for (auto& ev : tt.ev) HIP_TRY(hipEventCreate(&ev));
-    HIP_TRY(hipMemsetAsync(e->d_planes.p, 0x5a, (size_t)n * e->d.planes * e->cfg.plane_words * 8, e->stream));
+    HIP_TRY(hipMemsetAsync(L.d_planes.p, 0x5a, (size_t)n * e->d.planes * e->cfg.plane_words * 8, L.stream));
     double total_ms = 0;
     int rc = CATTUS_OK;
     for (uint32_t rep = 0; rep < reps + 1 && rc == CATTUS_OK; rep++) {  // first pass is warm-up
         tt.used = 0;
-        rc = enqueue_forward(e, e->d_planes.as<uint64_t>(), n, e->d_policy.as<float>(), e->d_value.as<float>(), e->stream, &tt);
+        rc = enqueue_forward(e, L, L.d_planes.as<uint64_t>(), n, L.d_policy.as<float>(), L.d_value.as<float>(), L.stream, &tt);
         if (rc) break;
-        hipError_t err = hipStreamSynchronize(e->stream);
+        hipError_t err = hipStreamSynchronize(L.stream);
         if (err != hipSuccess) {
             rc = fail(CATTUS_E_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(err));
             break;

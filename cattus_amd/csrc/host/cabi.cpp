@@ -50,6 +50,7 @@ SelfPlayConfig to_config(const cattus_sp_config* c) {
     cfg.game_stride = std::max(1u, c->game_stride);
     cfg.host_alloc = c->host_alloc;
     cfg.host_free = c->host_free;
+    cfg.eval_threads = c->eval_threads ? std::min(c->eval_threads, 8u) : 2;
     return cfg;
 }
 
@@ -223,7 +224,9 @@ SP_API int cattus_sp_run(int game, const cattus_sp_config* c, cattus_net_eval_fn
     dispatch(game, [&](auto g) -> int {
         typedef decltype(g) G;
         const bool same = net2 == nullptr;
-        SelfPlayRunner<G> runner(to_config(c), NetHandle{net1, ctx1}, same ? NetHandle{net1, ctx1} : NetHandle{net2, ctx2}, same);
+        const NetHandle h1{net1, ctx1, c->legal_net1};
+        const NetHandle h2 = same ? h1 : NetHandle{net2, ctx2, c->legal_net2};
+        SelfPlayRunner<G> runner(to_config(c), h1, h2, same);
         auto res = std::make_unique<cattus_sp_result>();
         SelfPlayResult r;
         rc = runner.generate_data(games_num, out_dir1 ? out_dir1 : "", out_dir2 ? out_dir2 : "", &res->records, r);

@@ -35,9 +35,15 @@ namespace cattus {
 // Raw network callback: planes [n][PLANES][PLANE_WORDS] -> policy [n][MOVES], value [n]; 0 = ok.
 typedef int (*net_eval_fn)(void* ctx, const uint64_t* planes, uint32_t n, float* policy, float* value);
 
+// Network callback that also does calc_moves_probs (net/mod.rs:100-119): legal_idx [n][stride] policy
+// indices of each leaf's legal moves, legal_count [n] -> probs [n][stride], value [n]; 0 = ok.
+typedef int (*net_eval_legal_fn)(void* ctx, const uint64_t* planes, uint32_t n, const uint16_t* legal_idx,
+                                 const uint16_t* legal_count, uint32_t legal_stride, float* probs, float* value);
+
 struct NetHandle {
     net_eval_fn fn = nullptr;
     void* ctx = nullptr;
+    net_eval_legal_fn legal_fn = nullptr;  // when set, used instead of fn
 };
 
 struct Metrics {
@@ -114,6 +120,10 @@ struct PendingLeaf {
     typename G::Position pos;  // flipped so that Player1 is to move
     bool flipped = false;
     uint64_t planes[G::PLANES * G::PLANE_WORDS];
+    // networks with legal_fn only: the legal moves of pos and their policy indices
+    std::vector<typename G::Move> moves;
+    uint16_t legal_idx[G::MOVES < 224 ? G::MOVES : 224];
+    uint32_t legal_count = 0;
 };
 
 template <typename G>
@@ -132,7 +142,22 @@ class NetValueFunction {
             return true;
         }
         pend.pos.planes(pend.planes);
+        if (net_.legal_fn) {
+            pend.pos.legal_moves(pend.moves);
+            pend.legal_count = (uint32_t)pend.moves.size();  // the driver rejects counts above the stride
+            const size_t m = std::min(pend.moves.size(), sizeof pend.legal_idx / sizeof pend.legal_idx[0]);
+            for (size_t i = 0; i < m; i++) pend.legal_idx[i] = (uint16_t)pend.moves[i].nn_idx();
+        }
         return false;
+    }
+    // the same tail as finish() for a network that returned the legal-move probabilities itself
+    void finish_legal(const PendingLeaf<G>& pend, const float* probs, float value, Evaluation<G>& out) {
+        out.probs.clear();
+        for (size_t i = 0; i < pend.moves.size(); i++) out.probs.emplace_back(pend.moves[i], probs[i]);
+        out.value = value;
+        if (cache_.insert(pend.pos, out, &out)) metrics_->cache_misses++;
+        else metrics_->cache_hits++;
+        unflip(out, pend.flipped);
     }
     // calc_moves_probs + cache insert + flip_score_if_needed (net/mod.rs:100-119, cache.rs:49-74, net/mod.rs:166-182)
     void finish(const PendingLeaf<G>& pend, const float* logits, float value, Evaluation<G>& out) {
@@ -226,6 +251,7 @@ struct SelfPlayConfig {
     uint32_t threads = 1;           // host worker threads advancing slots
     size_t cache_size = 1000;       // mcts.cache_size
     uint32_t concurrent_games = 0;  // slots; 0 -> max(threads, batch_size)
+    uint32_t eval_threads = 2;      // threads calling the network (batches in flight)
     uint64_t seed = 1;
     // this process plays global game indices first_game + k*game_stride, k = 0..games_num-1
     uint32_t first_game = 0, game_stride = 1;
@@ -246,6 +272,9 @@ class SelfPlayRunner {
    public:
     typedef typename G::Position Position;
     typedef typename G::Move Move;
+    // most legal moves a position can have (chess: 218 is the known maximum); row length of the
+    // legal-move buffers
+    static constexpr uint32_t LEGAL_STRIDE = G::MOVES < 224 ? G::MOVES : 224;
 
     SelfPlayRunner(const SelfPlayConfig& cfg, NetHandle net1, NetHandle net2, bool same_model)
         : cfg_(cfg), vf1_(net1, cfg.cache_size, &metrics_), vf2_(net2, cfg.cache_size, &metrics_), same_model_(same_model) {}
@@ -288,19 +317,31 @@ class SelfPlayRunner {
         for (uint32_t i = 0; i < nslots; i++) ready.push_back(i);
 
         // ring of batch buffers: a buffer is reusable once every leaf of its batch has been consumed
-        constexpr int NBUF = 4;
+        constexpr int NBUF = 6;
         struct BatchBuf {
             uint64_t* planes = nullptr;
             float *policy = nullptr, *value = nullptr;
+            uint16_t *legal_idx = nullptr, *legal_cnt = nullptr;  // networks with legal_fn: policy holds probs
             uint32_t refs = 0;  // guarded by mu
         } bufs[NBUF];
+        // Row length of the per-leaf result: all logits, or (legal_fn) one probability per legal move.
+        const bool legal = vf1_.net().legal_fn != nullptr;
+        if (legal != (vf2_.net().legal_fn != nullptr)) {
+            error_ = "both networks must be of the same kind";
+            return -4;
+        }
+        const size_t row = legal ? LEGAL_STRIDE : (size_t)G::MOVES;
         auto halloc = [&](size_t bytes) { return cfg_.host_alloc ? cfg_.host_alloc(bytes) : malloc(bytes); };
         auto hfree = [&](void* p) { cfg_.host_free ? cfg_.host_free(p) : free(p); };
         for (auto& b : bufs) {
             b.planes = (uint64_t*)halloc(cfg_.batch_size * words * 8);
-            b.policy = (float*)halloc((size_t)cfg_.batch_size * G::MOVES * 4);
+            b.policy = (float*)halloc((size_t)cfg_.batch_size * row * 4);
             b.value = (float*)halloc(cfg_.batch_size * 4);
-            if (!b.planes || !b.policy || !b.value) {
+            if (legal) {
+                b.legal_idx = (uint16_t*)halloc((size_t)cfg_.batch_size * LEGAL_STRIDE * 2);
+                b.legal_cnt = (uint16_t*)halloc((size_t)cfg_.batch_size * 2);
+            }
+            if (!b.planes || !b.policy || !b.value || (legal && (!b.legal_idx || !b.legal_cnt))) {
                 error_ = "cannot allocate batch buffers";
                 return -4;
             }
@@ -333,20 +374,25 @@ class SelfPlayRunner {
                     else done++;
                 }
                 (void)freed;
-                cv_eval.notify_one();
+                cv_eval.notify_all();
             }
         };
         std::vector<std::thread> workers;
         for (uint32_t i = 0; i < cfg_.threads; i++) workers.emplace_back(worker);
 
-        {
+        // Evaluation threads: each takes a batch of pending leaves through the network callback.  With two
+        // of them a second batch is prepared and in flight while the first one is on the GPU (the
+        // evaluator has one lane per concurrent caller).  A partial batch only goes out when nothing else
+        // can add to it: no slot is being advanced and no other batch is in flight.
+        uint32_t inflight = 0;
+        auto evaluator = [&]() {
             std::vector<uint32_t> who;
             std::unique_lock<std::mutex> lk(mu);
             for (;;) {
-                if (done == nslots || rc != 0) break;
+                if (done == nslots || rc != 0 || finished) break;
                 int netid = pending[0].size() >= pending[1].size() ? 0 : 1;
                 const bool full = pending[netid].size() >= cfg_.batch_size;
-                const bool drained = ready.empty() && busy == 0 && !pending[netid].empty();
+                const bool drained = ready.empty() && busy == 0 && inflight == 0 && !pending[netid].empty();
                 int bi = -1;
                 for (int i = 0; i < NBUF; i++)
                     if (bufs[i].refs == 0) bi = i;
@@ -359,24 +405,37 @@ class SelfPlayRunner {
                 who.assign(pending[netid].begin(), pending[netid].begin() + n);
                 pending[netid].erase(pending[netid].begin(), pending[netid].begin() + n);
                 bb.refs = (uint32_t)n;
+                inflight++;
                 lk.unlock();
-                for (size_t k = 0; k < n; k++) memcpy(bb.planes + k * words, slots[who[k]].pend.planes, words * 8);
+                int erc = 0;
+                for (size_t k = 0; k < n; k++) {
+                    const PendingLeaf<G>& pl = slots[who[k]].pend;
+                    memcpy(bb.planes + k * words, pl.planes, words * 8);
+                    if (legal) {
+                        if (pl.legal_count > LEGAL_STRIDE) erc = -5;
+                        bb.legal_cnt[k] = (uint16_t)std::min<uint32_t>(pl.legal_count, LEGAL_STRIDE);
+                        memcpy(bb.legal_idx + k * LEGAL_STRIDE, pl.legal_idx, (size_t)bb.legal_cnt[k] * 2);
+                    }
+                }
                 NetHandle net = netid == 0 ? vf1_.net() : vf2_.net();
                 const auto r0 = std::chrono::steady_clock::now();
-                const int erc = net.fn(net.ctx, bb.planes, (uint32_t)n, bb.policy, bb.value);
+                if (erc == 0)
+                    erc = legal ? net.legal_fn(net.ctx, bb.planes, (uint32_t)n, bb.legal_idx, bb.legal_cnt, LEGAL_STRIDE, bb.policy, bb.value)
+                                : net.fn(net.ctx, bb.planes, (uint32_t)n, bb.policy, bb.value);
                 if (erc == 0) {
                     metrics_.set_run(std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count());
                     metrics_.activation_count++;  // counts batches, as the reference does (net/mod.rs:68)
                     metrics_.node_evals += n;
                     for (size_t k = 0; k < n; k++) {
                         Slot& sl = slots[who[k]];
-                        sl.logits = bb.policy + k * (size_t)G::MOVES;
+                        sl.logits = bb.policy + k * row;
                         sl.value = bb.value[k];
                         sl.batch = bi;
                         sl.state = Slot::HAVE_RESULT;
                     }
                 }
                 lk.lock();
+                inflight--;
                 if (erc != 0) {
                     error_ = "network evaluation failed with status " + std::to_string(erc);
                     rc = erc;
@@ -387,9 +446,19 @@ class SelfPlayRunner {
             }
             finished = true;
             cv_work.notify_all();
+            cv_eval.notify_all();
+        };
+        {
+            std::vector<std::thread> evals;
+            for (uint32_t i = 1; i < std::max(1u, cfg_.eval_threads); i++) evals.emplace_back(evaluator);
+            evaluator();
+            for (auto& t : evals) t.join();
         }
         for (auto& t : workers) t.join();
-        for (auto& b : bufs) hfree(b.planes), hfree(b.policy), hfree(b.value);
+        for (auto& b : bufs) {
+            hfree(b.planes), hfree(b.policy), hfree(b.value);
+            if (b.legal_idx) hfree(b.legal_idx), hfree(b.legal_cnt);
+        }
         if (rc != 0) return rc;
         int frc = 0;
         for (auto& s : slots)
@@ -411,7 +480,7 @@ class SelfPlayRunner {
         bool repetition_detected = false;
         std::vector<std::pair<Position, std::vector<std::pair<Move, float>>>> pairs;
         PendingLeaf<G> pend;
-        const float* logits = nullptr;  // row of the batch buffer `batch` until consumed
+        const float* logits = nullptr;  // row (logits, or legal-move probabilities) of batch buffer `batch` until consumed
         int batch = -1;
         float value = 0;
         std::chrono::steady_clock::time_point search_t0;
@@ -473,7 +542,9 @@ class SelfPlayRunner {
                 }
                 case Slot::HAVE_RESULT: {
                     Evaluation<G> ev;
-                    (s.netid == 0 ? vf1_ : vf2_).finish(s.pend, s.logits, s.value, ev);
+                    auto& vf = s.netid == 0 ? vf1_ : vf2_;
+                    if (vf.net().legal_fn) vf.finish_legal(s.pend, s.logits, s.value, ev);
+                    else vf.finish(s.pend, s.logits, s.value, ev);
                     s.cur->deliver(ev);
                     s.logits = nullptr;  // the caller releases the batch buffer reference
                     s.state = Slot::SEARCHING;

@@ -95,6 +95,9 @@ void launch_value_fc1(const float* hv, uint32_t hv_stride, const float* w1t, con
 void launch_value_fc2_tanh(const float* h1, const float* w2, const float* b2, uint32_t b, float* value,
                            hipStream_t st);
 // policy[b][m] = scrub(sum_k wpt[k][m]*hv[b*hv_stride + off + k] + bp[m])
+// Softmax over each leaf's legal moves (net/mod.rs:100-119): idx [b][L] policy indices, cnt [b] <= L, probs [b][L].
+int launch_legal_softmax(const float* policy, uint32_t M, const uint16_t* idx, const uint16_t* cnt, uint32_t L, uint32_t b,
+                         float* probs, hipStream_t st);
 void launch_policy_fc(const float* hv, uint32_t hv_stride, uint32_t off, const float* wpt, const float* bp, uint32_t b,
                       uint32_t K, uint32_t M, float* policy, hipStream_t st);
 

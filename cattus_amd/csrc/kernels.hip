@@ -1333,6 +1333,54 @@ void launch_value_fc2_tanh(const float* h1, const float* w2, const float* b2, ui
     hipLaunchKernelGGL(value_fc2_tanh_kernel, dim3((b + 255) / 256), dim3(256), 0, st, h1, w2, b2, b, value);
 }
 
+// exp for x <= 0 from the same operations as exp_pos (arguments below -80 give 0), so that the
+// legal-move softmax below is reproducible bit for bit on the host.
+__device__ __forceinline__ float exp_nonpos(float x) { return x < -80.0f ? 0.0f : exp_pos(x); }
+
+// calc_moves_probs (engine/src/net/mod.rs:100-119) for one leaf per wave: gather the logits of the
+// leaf's legal moves, subtract their maximum, exponentiate, and divide by the sum taken in move
+// order (the order of the reference's iterator sum).
+__global__ void __launch_bounds__(64) legal_softmax_kernel(const float* __restrict__ policy, uint32_t M,
+                                                           const uint16_t* __restrict__ idx,
+                                                           const uint16_t* __restrict__ cnt, uint32_t L,
+                                                           float* __restrict__ probs) {
+    __shared__ float es[1024];
+    __shared__ float total;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = cnt[b] < L ? cnt[b] : L;
+    const float* row = policy + (size_t)b * M;
+    const uint16_t* ix = idx + (size_t)b * L;
+    float mx = -3.40282347e+38f;  // fold(f32::MIN, f32::max)
+    for (uint32_t i = lane; i < n; i += 64) {
+        const float v = row[ix[i]];
+        es[i] = v;
+        mx = v > mx ? v : mx;
+    }
+    for (int off = 32; off; off >>= 1) {
+        const float o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    for (uint32_t i = lane; i < n; i += 64) es[i] = exp_nonpos(es[i] - mx);
+    __syncthreads();
+    if (lane == 0) {
+        float s = 0.0f;
+        for (uint32_t i = 0; i < n; i++) s += es[i];
+        total = s;
+    }
+    __syncthreads();
+    const float s = total;
+    float* out = probs + (size_t)b * L;
+    for (uint32_t i = lane; i < L; i += 64) out[i] = i < n ? es[i] / s : 0.0f;
+}
+
+int launch_legal_softmax(const float* policy, uint32_t M, const uint16_t* idx, const uint16_t* cnt, uint32_t L, uint32_t b,
+                         float* probs, hipStream_t st) {
+    if (L > 1024) return -1;
+    if (!b) return 0;
+    hipLaunchKernelGGL(legal_softmax_kernel, dim3(b), dim3(64), 0, st, policy, M, idx, cnt, L, probs);
+    return 0;
+}
+
 // Block = 256 logits x 8 leaves; the 8 input rows are staged in LDS, every weight is loaded once
 // (coalesced along m) and used for 8 fmaf.
 constexpr int PFC_ROWS = 8;

@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "cattus_hip_desc",
     "cattus_hip_eval",
     "cattus_hip_eval_device",
+    "cattus_hip_eval_legal",
     "cattus_hip_submit",
     "cattus_hip_wait",
     "cattus_hip_flush",
@@ -99,6 +100,8 @@ def load_library():
     L.cattus_hip_desc.argtypes = [vp, C.POINTER(NetDescC)]
     L.cattus_hip_eval.argtypes = [vp, u64p, C.c_uint32, f32p, f32p]
     L.cattus_hip_eval_device.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+    u16p = C.POINTER(C.c_uint16)
+    L.cattus_hip_eval_legal.argtypes = [vp, u64p, C.c_uint32, u16p, u16p, C.c_uint32, f32p, f32p]
     L.cattus_hip_submit.argtypes = [vp, u64p, C.POINTER(C.c_uint64)]
     L.cattus_hip_wait.argtypes = [vp, C.c_uint64, f32p, f32p]
     L.cattus_hip_flush.argtypes = [vp]
@@ -204,6 +207,28 @@ class HipEvaluator:
         value = np.empty((n,), dtype=np.float32)
         _check(self._lib.cattus_hip_eval(self._h, _u64(planes), n, _f32(policy), _f32(value)))
         return policy, value
+
+    def eval_legal(self, planes, legal_idx, legal_count) -> tuple[np.ndarray, np.ndarray]:
+        """``eval`` + ``calc_moves_probs`` (net/mod.rs:100-119) on the device.
+
+        legal_idx uint16 ``[n, L]``, legal_count uint16 ``[n]`` -> (probs ``[n, L]``, values ``[n]``).
+        """
+        planes = self._planes(planes)
+        n = planes.shape[0]
+        legal_idx = np.ascontiguousarray(legal_idx, dtype=np.uint16)
+        legal_count = np.ascontiguousarray(legal_count, dtype=np.uint16)
+        if legal_idx.ndim != 2 or legal_idx.shape[0] != n or legal_count.shape != (n,):
+            raise ValueError("legal_idx must be [n, L] and legal_count [n]")
+        probs = np.empty(legal_idx.shape, dtype=np.float32)
+        value = np.empty((n,), dtype=np.float32)
+        u16 = C.POINTER(C.c_uint16)
+        _check(
+            self._lib.cattus_hip_eval_legal(
+                self._h, _u64(planes), n, legal_idx.ctypes.data_as(u16), legal_count.ctypes.data_as(u16),
+                legal_idx.shape[1], _f32(probs), _f32(value),
+            )
+        )
+        return probs, value
 
     def run_net(self, planes) -> list[tuple[np.ndarray, float]]:
         """``NNetwork::run_net`` (net/mod.rs:41-72): one ``(logits, value)`` pair per leaf."""

@@ -25,6 +25,10 @@ LIB_PATH = _PKG / "libcattus_selfplay.so"
 GAMES = {"tictactoe": 0, "ttt": 0, "hex4": 1, "hex5": 2, "hex7": 3, "hex9": 4, "hex11": 5, "chess": 6}
 
 NET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+NET_LEGAL_FN = C.CFUNCTYPE(
+    C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_uint32,
+    C.POINTER(C.c_float), C.POINTER(C.c_float),
+)
 
 ABI_SYMBOLS = [
     "cattus_sp_game_info",
@@ -71,6 +75,9 @@ class SpConfig(C.Structure):
         ("game_stride", C.c_uint32),
         ("host_alloc", C.c_void_p),
         ("host_free", C.c_void_p),
+        ("legal_net1", C.c_void_p),
+        ("legal_net2", C.c_void_p),
+        ("eval_threads", C.c_uint32),
     ]
 
 
@@ -170,6 +177,7 @@ def make_config(
     seed: int = 1,
     first_game: int = 0,
     game_stride: int = 1,
+    eval_threads: int = 0,
 ) -> SpConfig:
     c = SpConfig()
     c.struct_size = C.sizeof(SpConfig)
@@ -182,6 +190,7 @@ def make_config(
     c.prior_noise_alpha, c.prior_noise_epsilon = prior_noise_alpha, prior_noise_epsilon
     c.cache_size, c.batch_size, c.threads = cache_size, batch_size, max(1, min(threads, available_cpus()))
     c.concurrent_games, c.seed, c.first_game, c.game_stride = concurrent_games, seed, first_game, game_stride
+    c.eval_threads = eval_threads  # 0 = the driver's default (2 batches in flight)
     return c
 
 
@@ -207,6 +216,7 @@ class Net:
 
     def __init__(self, fn_addr: int, ctx: int, keepalive=None):
         self.fn_addr, self.ctx, self._keep = fn_addr, ctx, keepalive
+        self.legal_addr = None  # a cattus_net_eval_legal_fn: the network also does calc_moves_probs
 
     @staticmethod
     def stub(game: str) -> "Net":
@@ -216,10 +226,16 @@ class Net:
         return Net(C.cast(L.cattus_sp_stub_net, C.c_void_p).value, C.addressof(ctx), keepalive=ctx)
 
     @staticmethod
-    def hip(evaluator) -> "Net":
-        """libcattus_hip's cattus_hip_eval has exactly the callback signature; ctx = evaluator handle."""
+    def hip(evaluator, device_softmax: bool = False) -> "Net":
+        """libcattus_hip's cattus_hip_eval has exactly the callback signature; ctx = evaluator handle.
+
+        device_softmax: use cattus_hip_eval_legal, i.e. the softmax over each leaf's legal moves
+        (net/mod.rs:100-119) runs on the GPU and only those probabilities cross PCIe.
+        """
         fn = C.cast(evaluator._lib.cattus_hip_eval, C.c_void_p).value
         net = Net(fn, evaluator._h.value, keepalive=evaluator)
+        if device_softmax:
+            net.legal_addr = C.cast(evaluator._lib.cattus_hip_eval_legal, C.c_void_p).value
         # page-locked batch buffers: the evaluator then transfers without a staging copy
         net.host_alloc = C.cast(evaluator._lib.cattus_hip_host_alloc, C.c_void_p).value
         net.host_free = C.cast(evaluator._lib.cattus_hip_host_free, C.c_void_p).value
@@ -250,6 +266,36 @@ class Net:
         net._cb = cb
         return net
 
+    @staticmethod
+    def python_legal(fn) -> "Net":
+        """Wrap ``fn(planes [n, words], legal_idx [n, L], legal_count [n]) -> (probs [n, L], value [n])`` (tests only)."""
+
+        def trampoline(_ctx, planes_p, n, idx_p, cnt_p, stride, probs_p, value_p):
+            try:
+                words = Net._words[id(cb)]
+                planes = np.ctypeslib.as_array(planes_p, shape=(n, words)).copy()
+                idx = np.ctypeslib.as_array(idx_p, shape=(n, stride)).copy()
+                cnt = np.ctypeslib.as_array(cnt_p, shape=(n,)).copy()
+                probs, value = fn(planes, idx, cnt)
+                probs = np.ascontiguousarray(probs, dtype=np.float32)
+                value = np.ascontiguousarray(value, dtype=np.float32)
+                assert probs.shape == (n, stride)
+                C.memmove(probs_p, probs.ctypes.data, probs.nbytes)
+                C.memmove(value_p, value.ctypes.data, value.nbytes)
+                return 0
+            except Exception:  # pragma: no cover - surfaced as a status code
+                import traceback
+
+                traceback.print_exc()
+                return -99
+
+        cb = NET_LEGAL_FN(trampoline)
+        stub = NET_FN(lambda *a: -98)  # never called: the driver uses legal_addr
+        net = Net(C.cast(stub, C.c_void_p).value, 0, keepalive=(cb, stub))
+        net.legal_addr = C.cast(cb, C.c_void_p).value
+        net._cb = cb
+        return net
+
     _words: dict = {}
 
     def bind_words(self, words: int):
@@ -274,6 +320,8 @@ def run_self_play(game: str, cfg: SpConfig, net1: Net, net2: Net | None, games_n
             os.makedirs(d, exist_ok=True)
     if getattr(net1, "host_alloc", None) and (net2 is None or getattr(net2, "host_alloc", None)):
         cfg.host_alloc, cfg.host_free = net1.host_alloc, net1.host_free
+    cfg.legal_net1 = net1.legal_addr
+    cfg.legal_net2 = net2.legal_addr if net2 is not None else None
     res = C.c_void_p()
     rc = L.cattus_sp_run(
         GAMES[game], C.byref(cfg), net1.fn_addr, net1.ctx, net2.fn_addr if net2 else None, net2.ctx if net2 else None,

@@ -75,6 +75,16 @@ int cattus_hip_desc(const cattus_eval* e, cattus_net_desc* out);
  * planes: [n][planes][plane_words] u64 host memory; policy: [n][moves]; value: [n]. */
 int cattus_hip_eval(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy, float* value);
 
+/* cattus_hip_eval followed by calc_moves_probs (engine/src/net/mod.rs:100-119) on the device: the
+ * logits stay in HBM and each leaf's softmax over its legal moves comes back instead.
+ * legal_idx: [n][legal_stride] policy indices (Move::to_nn_idx) of the leaf's legal moves, in the
+ * order the caller wants the probabilities; legal_count: [n], each <= legal_stride <= 1024;
+ * probs: [n][legal_stride], entries past legal_count[i] are 0.  max = fold(f32::MIN, max), the sum
+ * runs in move order, exp is the evaluator's own, so a host restatement
+ * reproduces the result bit for bit. */
+int cattus_hip_eval_legal(cattus_eval* e, const uint64_t* planes, uint32_t n, const uint16_t* legal_idx,
+                          const uint16_t* legal_count, uint32_t legal_stride, float* probs, float* value);
+
 /* Same with every buffer already resident in device memory (HBM) and asynchronous on `stream`
  * (a hipStream_t; NULL = the evaluator's own stream).  Used by bench.py so that the timed
  * region excludes PCIe. */

@@ -32,6 +32,12 @@ typedef enum cattus_game {
 /* planes [n][planes][plane_words] -> policy [n][moves], value [n]; returns 0 on success */
 typedef int (*cattus_net_eval_fn)(void* ctx, const uint64_t* planes, uint32_t n, float* policy, float* value);
 
+/* A network that also computes calc_moves_probs (engine/src/net/mod.rs:100-119), e.g. cattus_hip_eval_legal:
+ * legal_idx [n][legal_stride] policy indices of each leaf's legal moves, legal_count [n] ->
+ * probs [n][legal_stride], value [n]; returns 0 on success */
+typedef int (*cattus_net_eval_legal_fn)(void* ctx, const uint64_t* planes, uint32_t n, const uint16_t* legal_idx,
+                                        const uint16_t* legal_count, uint32_t legal_stride, float* probs, float* value);
+
 /* The engine JSON of the reference (self_play_cmd.rs:34-53) plus the sharding fields. */
 typedef struct cattus_sp_config {
     uint32_t struct_size;
@@ -51,6 +57,12 @@ typedef struct cattus_sp_config {
      * cattus_hip_host_alloc / cattus_hip_host_free the evaluator DMAs straight into them */
     void* (*host_alloc)(size_t);
     void (*host_free)(void*);
+    /* optional: when set, player k's leaves go to legal_netk(ctxk, ...) instead of netk and the host
+     * skips its own softmax; set both or neither when two networks play */
+    cattus_net_eval_legal_fn legal_net1, legal_net2;
+    /* threads calling the network = batches in flight (0 = 2).  libcattus_hip serves two callers
+     * concurrently (one lane each), which hides transfers and launch latency behind the other batch */
+    uint32_t eval_threads;
 } cattus_sp_config;
 
 typedef struct cattus_sp_summary {

@@ -40,6 +40,8 @@ def lib():
         L.oracle_net_folded_conv.restype = C.c_int
         L.oracle_softmax_legal.argtypes = [f32p, u32p, C.c_uint32, f32p]
         L.oracle_softmax_legal.restype = None
+        L.oracle_softmax_legal_det.argtypes = [f32p, C.POINTER(C.c_uint16), C.c_uint32, f32p]
+        L.oracle_softmax_legal_det.restype = None
         L.oracle_tanhf.argtypes = [C.c_float]
         L.oracle_tanhf.restype = C.c_float
         _LIB = L
@@ -126,6 +128,15 @@ def softmax_legal(logits: np.ndarray, idx: np.ndarray) -> np.ndarray:
     idx = np.ascontiguousarray(idx, dtype=np.uint32)
     out = np.empty((len(idx),), dtype=np.float32)
     lib().oracle_softmax_legal(_p(logits, C.c_float), _p(idx, C.c_uint32), len(idx), _p(out, C.c_float))
+    return out
+
+
+def softmax_legal_det(logits: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """The device softmax of cattus_hip_eval_legal restated (evaluator's exp, move-order sum)."""
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    idx = np.ascontiguousarray(idx, dtype=np.uint16)
+    out = np.empty((len(idx),), dtype=np.float32)
+    lib().oracle_softmax_legal_det(_p(logits, C.c_float), _p(idx, C.c_uint16), len(idx), _p(out, C.c_float))
     return out
 
 

@@ -73,7 +73,7 @@ typedef struct oracle_net {
 /* ---------------------------------------------------------------- tanh --- */
 
 static inline float oracle_expf_pos(float x) {
-    /* exp(x) for 0 <= x <= 40 : n = rint(x*log2e), r = x - n*ln2 (two-part), degree-6 poly */
+    /* exp(x) for -80 <= x <= 40 : n = rint(x*log2e), r = x - n*ln2 (two-part), degree-6 poly */
     const float log2e = 1.44269504088896341f;
     const float ln2_hi = 0.693145751953125f;        /* 0x3f317200 */
     const float ln2_lo = 1.42860682030941723e-06f;  /* ln2 - ln2_hi */
@@ -89,7 +89,7 @@ static inline float oracle_expf_pos(float x) {
     p = fmaf(p, r, 1.0f);
     union { float f; uint32_t u; } v;
     v.f = p;
-    v.u += ((uint32_t)(int32_t)n) << 23; /* p in [0.7,1.5), n in [0,58]: stays normal */
+    v.u += ((uint32_t)(int32_t)n) << 23; /* p in [0.7,1.5), n in [-116,58]: stays normal */
     return v.f;
 }
 
@@ -487,6 +487,24 @@ ORACLE_API void oracle_softmax_legal(const float *logits, const uint32_t *idx, u
     float sum = 0.0f;
     for (uint32_t i = 0; i < k; i++) {
         probs[i] = expf(logits[idx[i]] - max_p);
+        sum += probs[i];
+    }
+    for (uint32_t i = 0; i < k; i++) probs[i] = probs[i] / sum;
+}
+
+/* The same softmax with the evaluator's own exp (arguments below -80 give 0): the restatement that
+ * cattus_hip_eval_legal's device kernel is held to bit for bit.  Differs from oracle_softmax_legal
+ * only by libm's expf rounding (a few ulp). */
+ORACLE_API void oracle_softmax_legal_det(const float *logits, const uint16_t *idx, uint32_t k, float *probs) {
+    float max_p = -3.40282347e+38f;
+    for (uint32_t i = 0; i < k; i++) {
+        float s = logits[idx[i]];
+        max_p = s > max_p ? s : max_p;
+    }
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < k; i++) {
+        float x = logits[idx[i]] - max_p;
+        probs[i] = x < -80.0f ? 0.0f : oracle_expf_pos(x);
         sum += probs[i];
     }
     for (uint32_t i = 0; i < k; i++) probs[i] = probs[i] / sum;

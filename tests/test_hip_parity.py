@@ -218,3 +218,55 @@ def test_persistent_tower_equals_per_layer_launches(monkeypatch):
             for n in (256, 37, 4):
                 p1, v1 = ev.eval(planes[:n])
                 assert (p1 == p0[:n]).all() and (v1 == v0[:n]).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_eval_legal_softmax_bit_exact_vs_restatement(dtype):
+    """cattus_hip_eval_legal = cattus_hip_eval + calc_moves_probs (net/mod.rs:100-119) on the device:
+    bit-exact against the oracle's restatement applied to the same evaluator's logits, within 1e-6 of
+    the libm softmax, zero past each leaf's count; ragged counts including 1 and the full stride."""
+    d = NetDesc(**CHESS, blocks=2, filters=64, vhc=8, phc=8)
+    blob = seeded_blob(d, 21)
+    n, L = 37, 224
+    planes = synth.random_chess_planes(n, 3)
+    rng = np.random.default_rng(1)
+    cnt = rng.integers(1, L + 1, size=n).astype(np.uint16)
+    cnt[0], cnt[1], cnt[2] = 1, L, 2
+    idx = np.zeros((n, L), dtype=np.uint16)
+    for i in range(n):
+        idx[i, : cnt[i]] = rng.choice(d.moves, cnt[i], replace=False)
+    with HipEvaluator(blob, batch_size=64, plane_words=1, dtype=dtype) as ev:
+        pol, val = ev.eval(planes)
+        probs, val2 = ev.eval_legal(planes, idx, cnt)
+        assert (val == val2).all()
+        for i in range(n):
+            c = int(cnt[i])
+            want = oracle.softmax_legal_det(pol[i], idx[i, :c])
+            assert (probs[i, :c] == want).all(), (i, np.abs(probs[i, :c] - want).max())
+            assert (probs[i, c:] == 0).all()
+            libm = oracle.softmax_legal(pol[i], idx[i, :c].astype(np.uint32))
+            assert np.abs(probs[i, :c] - libm).max() <= 1e-6
+        # argument checks
+        bad = idx.copy()
+        bad[3, 0] = d.moves
+        with pytest.raises(CattusHipError):
+            ev.eval_legal(planes, bad, cnt)
+        with pytest.raises(CattusHipError):
+            ev.eval_legal(planes, idx[:, :100], cnt)  # count > stride
+
+
+def test_eval_legal_scrubbed_logits_get_zero_probability():
+    # a non-finite logit is scrubbed to f32::MIN (net/mod.rs:56-61); its softmax weight is exactly 0
+    from cattus_amd.weights import pack_tensors, seeded_tensors
+
+    d = NetDesc(**hex_game(4), blocks=1, filters=64, vhc=4, phc=4)
+    t = seeded_tensors(d, 5)
+    t["_policy_head.2.bias"][3] = np.inf
+    blob = pack_tensors(d, t)
+    planes = synth.random_hex_planes(2, 4, 9)
+    idx = np.tile(np.arange(16, dtype=np.uint16), (2, 1))
+    cnt = np.array([16, 5], dtype=np.uint16)
+    with HipEvaluator(blob, batch_size=4, plane_words=2, dtype="f32") as ev:
+        probs, _ = ev.eval_legal(planes, idx, cnt)
+    assert (probs[:, 3] == 0).all()
+    assert abs(probs[0].sum() - 1) < 1e-5 and abs(probs[1, :5].sum() - 1) < 1e-5 and (probs[1, 5:] == 0).all()

@@ -71,7 +71,8 @@ def test_first_record_matches_search_trace():
 @pytest.mark.parametrize("game", ["tictactoe", "hex4"])
 def test_results_independent_of_schedule(game):
     ref = sp.run_self_play(game, _cfg(), sp.Net.stub(game), None, 8)
-    for kw in (dict(threads=4, batch_size=4), dict(threads=3, batch_size=2, concurrent_games=8), dict(threads=2, batch_size=8, concurrent_games=5)):
+    for kw in (dict(threads=4, batch_size=4), dict(threads=3, batch_size=2, concurrent_games=8), dict(threads=2, batch_size=8, concurrent_games=5),
+               dict(threads=3, batch_size=2, concurrent_games=8, eval_threads=1), dict(threads=2, batch_size=2, concurrent_games=8, eval_threads=4)):
         got = sp.run_self_play(game, _cfg(**kw), sp.Net.stub(game), None, 8)
         assert (got["record_meta"] == ref["record_meta"]).all()
         assert (got["record_bytes"] == ref["record_bytes"]).all()
@@ -149,3 +150,44 @@ def test_config1_plumbing_run_hex4_with_oracle_network():
     res = sp.run_self_play("hex4", cfg, sp.Net.python(eval_planes), None, 2)
     assert res["player1_wins"] + res["player2_wins"] + res["draws"] == 2
     assert len([m for m in res["record_meta"] if m[0] == 0]) == len(trace)
+
+
+def _hashed_logits(planes, moves):
+    # cheap deterministic "network": logits and value from the plane words
+    h = (planes.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).sum(axis=1)
+    k = np.arange(moves, dtype=np.uint64)[None, :]
+    x = (h[:, None] ^ (k * np.uint64(0xC2B2AE3D27D4EB4F))) * np.uint64(0xD6E8FEB86659FD93)
+    pol = ((x >> np.uint64(40)).astype(np.float32) / np.float32(1 << 24) - 0.5) * 6.0
+    val = (((h >> np.uint64(40)).astype(np.float32)) / np.float32(1 << 24) - 0.5) * 0.6
+    return pol.astype(np.float32), val.astype(np.float32)
+
+
+@pytest.mark.parametrize("game,moves", [("tictactoe", 9), ("hex5", 25), ("chess", 1880)])
+def test_legal_softmax_network_gives_the_same_games(game, moves):
+    """A network that returns the softmax over the legal moves itself (cattus_net_eval_legal_fn, the
+    host side of cattus_hip_eval_legal) must see the legal moves of the flipped position, in move order,
+    and lead to the same records as the host's own calc_moves_probs (net/mod.rs:100-119)."""
+    seen = {"leaves": 0, "max_cnt": 0}
+
+    def plain(planes):
+        return _hashed_logits(planes, moves)
+
+    def legal(planes, idx, cnt):
+        pol, val = _hashed_logits(planes, moves)
+        probs = np.zeros(idx.shape, dtype=np.float32)
+        for i in range(len(planes)):
+            c = int(cnt[i])
+            assert 0 < c <= idx.shape[1] and len(set(idx[i, :c].tolist())) == c
+            probs[i, :c] = oracle.softmax_legal(pol[i], idx[i, :c].astype(np.uint32))
+            seen["leaves"] += 1
+            seen["max_cnt"] = max(seen["max_cnt"], c)
+        return probs, val
+
+    sims = 12 if game == "chess" else 30
+    kw = dict(sim_num=sims, batch_size=4, threads=2, concurrent_games=4)
+    a = sp.run_self_play(game, _cfg(**kw), sp.Net.python(plain), None, 2)
+    b = sp.run_self_play(game, _cfg(**kw), sp.Net.python_legal(legal), None, 2)
+    assert (a["record_meta"] == b["record_meta"]).all()
+    assert (a["record_bytes"] == b["record_bytes"]).all()
+    assert a["node_evals"] == b["node_evals"] == seen["leaves"]
+    assert seen["max_cnt"] <= moves

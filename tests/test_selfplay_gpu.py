@@ -73,3 +73,27 @@ def test_self_player_cli_contract(tmp_path):
     assert n > 0
     for f in (tmp_path / "o1").iterdir():
         assert f.stat().st_size == records.record_nbytes("hex5")
+
+
+@pytest.mark.parametrize("game,desc,words", [("hex7", dict(**hex_game(7), blocks=2, filters=64, vhc=16, phc=16), 2), ("chess", dict(**CHESS, blocks=2, filters=64, vhc=8, phc=8), 1)])
+def test_device_softmax_games_equal_host_restatement(game, desc, words):
+    """cattus_hip_eval_legal inside the driver: the records equal those of a driver whose network is
+    'HIP logits + the oracle's restatement of the device softmax' (bit-exact), and stay within 1e-6 of
+    the probabilities the host's libm softmax gives."""
+    d = NetDesc(**desc)
+    blob = seeded_blob(d, 5)
+    cfg = sp.make_config(sim_num=20, batch_size=8, threads=3, concurrent_games=8, cache_size=100000)
+    with HipEvaluator(blob, batch_size=8, plane_words=words, dtype="f32") as ev:
+
+        def restated(planes, idx, cnt):
+            pol, val = ev.eval(planes.reshape(len(planes), d.planes, words))
+            probs = np.zeros(idx.shape, dtype=np.float32)
+            for i in range(len(planes)):
+                probs[i, : cnt[i]] = oracle.softmax_legal_det(pol[i], idx[i, : cnt[i]])
+            return probs, val
+
+        got = sp.run_self_play(game, cfg, sp.Net.hip(ev, device_softmax=True), None, 4)
+        want = sp.run_self_play(game, cfg, sp.Net.python_legal(restated), None, 4)
+    assert got["node_evals"] == want["node_evals"] > 0
+    assert (got["record_meta"] == want["record_meta"]).all()
+    assert (got["record_bytes"] == want["record_bytes"]).all()
