@@ -139,7 +139,8 @@ def selfplay_leg(ev_blob, d, dtype: str, local_rank: int, rank: int, world: int,
         res = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, games, keep_records=False)
         dt = time.perf_counter() - t0
     return dict(seconds=dt, games=games, node_evals=res["node_evals"], batches=res["activation_count"], positions=res["positions"],
-                threads=threads, slots=slots, sims=sims)
+                threads=threads, slots=slots, sims=sims, steady_rate=res["steady_node_evals"] / max(res["steady_seconds"], 1e-9),
+                steady_seconds=res["steady_seconds"])
 
 
 def measured_traffic(kernel: str):
@@ -217,7 +218,8 @@ def main():
     sp_out = None
     if args.selfplay_games > 0 and args.workload == "chess20x256":
         leg = selfplay_leg(blob, d, args.dtype, local_rank, rank, world, args.selfplay_games, args.selfplay_sims)
-        t = torch.tensor([leg["seconds"], leg["games"], leg["node_evals"], leg["batches"], leg["positions"]], dtype=torch.float64, device=dev)
+        t = torch.tensor([leg["seconds"], leg["games"], leg["node_evals"], leg["batches"], leg["positions"], leg["steady_rate"]],
+                         dtype=torch.float64, device=dev)
         tmax = t.clone()
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -226,6 +228,9 @@ def main():
         sp_out = {
             "games_per_hour": float(t[1].item()) * 3600.0 / secs,
             "node_evals_per_sec": float(t[2].item()) / secs,
+            # while >= 3/4 of the concurrent-game slots still have a game to play, i.e. without the drain at
+            # the end of this fixed-size run when batches can no longer be filled (sum over GPUs)
+            "steady_node_evals_per_sec": float(t[5].item()),
             "games": int(t[1].item()),
             "sims_per_move": leg["sims"],
             "plies_per_game": float(t[4].item()) / max(1.0, float(t[1].item())),

@@ -242,6 +242,7 @@ SP_API int cattus_sp_run(int game, const cattus_sp_config* c, cattus_net_eval_fn
         s.cache_hits = m.cache_hits, s.cache_misses = m.cache_misses;
         s.run_duration = m.run_duration_ema, s.search_duration = m.search_duration_ema;
         s.seconds = r.seconds;
+        s.steady_seconds = r.steady_seconds, s.steady_node_evals = r.steady_node_evals;
         res->record_bytes = Serializer<G>::RECORD_BYTES;
         if (!keep_records) res->records.clear();
         std::sort(res->records.begin(), res->records.end(), [](const Record& a, const Record& b) {

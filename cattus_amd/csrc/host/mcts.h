@@ -94,6 +94,9 @@ class MctsPlayer {
         assert(p.sim_num > 0 && p.explore_factor >= 0 && p.prior_noise_alpha >= 0);
     }
 
+    // restart the random stream (temperature sampling, Dirichlet noise)
+    void reseed(uint64_t seed) { rng_ = Rng(seed); }
+
     // calc_moves_probabilities, first half (mcts/mod.rs:335-358): tree reuse, root creation.
     void begin_search(const std::vector<Position>& history) {
         assert(params_.sim_num > 1);  // develop_tree asserts this (mcts/mod.rs:157)

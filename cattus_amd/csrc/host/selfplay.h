@@ -265,6 +265,10 @@ struct SelfPlayResult {
     uint32_t w1 = 0, w2 = 0, d = 0;
     uint64_t positions = 0;
     double seconds = 0;
+    // the part of the run with at least 3/4 of the slots still playing (before the drain at the end,
+    // when the last games finish and batches can no longer be filled)
+    double steady_seconds = 0;
+    uint64_t steady_node_evals = 0;
 };
 
 template <typename G>
@@ -347,15 +351,30 @@ class SelfPlayRunner {
             }
         }
 
+#ifdef CATTUS_SCHED_STATS
+        // diagnostics: where the worker threads spend their time (summed over workers, seconds)
+        std::atomic<uint64_t> st_wait{0}, st_lock{0}, st_adv{0}, st_iters{0};
+        auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+#define SCHED_T(var) const uint64_t var = now_ns()
+#define SCHED_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define SCHED_T(var)
+#define SCHED_ADD(acc, a, b)
+#endif
         auto worker = [&]() {
-            constexpr size_t CHUNK = 4;  // slots taken per lock acquisition
+            constexpr size_t CHUNK = 16;  // most slots taken per lock acquisition
             uint32_t mine[CHUNK];
             std::unique_lock<std::mutex> lk(mu);
             for (;;) {
+                SCHED_T(w0);
                 cv_work.wait(lk, [&] { return finished || !ready.empty(); });
+                SCHED_T(w1);
+                SCHED_ADD(st_wait, w0, w1);
                 if (finished) return;
+                // an even share of what is ready, so that a burst of results spreads over all workers
+                const size_t take = std::min<size_t>(CHUNK, std::max<size_t>(2, ready.size() / (2 * cfg_.threads)));
                 size_t k = 0;
-                while (k < CHUNK && !ready.empty()) mine[k++] = ready.front(), ready.pop_front();
+                while (k < take && !ready.empty()) mine[k++] = ready.front(), ready.pop_front();
                 busy += (uint32_t)k;
                 lk.unlock();
                 int released[CHUNK];
@@ -364,17 +383,29 @@ class SelfPlayRunner {
                     released[i] = sl.state == Slot::HAVE_RESULT ? sl.batch : -1;
                     advance(sl, next_game, games_num, out_dir1, out_dir2, records, res, out_mu);
                 }
+                SCHED_T(a1);
+                SCHED_ADD(st_adv, w1, a1);
                 lk.lock();
+                SCHED_T(l1);
+                SCHED_ADD(st_lock, a1, l1);
+#ifdef CATTUS_SCHED_STATS
+                st_iters++;
+#endif
                 busy -= (uint32_t)k;
-                bool freed = false;
+                bool wake = false;  // something an evaluation thread may be waiting for has happened
                 for (size_t i = 0; i < k; i++) {
                     Slot& sl = slots[mine[i]];
-                    if (released[i] >= 0 && --bufs[released[i]].refs == 0) freed = true;
+                    if (released[i] >= 0 && --bufs[released[i]].refs == 0) wake = true;
                     if (sl.state == Slot::WAIT_EVAL) pending[sl.netid].push_back(mine[i]);
-                    else done++;
+                    else done++, wake = true;
                 }
-                (void)freed;
-                cv_eval.notify_all();
+                if (res.steady_seconds == 0 && (uint64_t)(nslots - done) * 4 < (uint64_t)nslots * 3) {
+                    res.steady_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    res.steady_node_evals = metrics_.node_evals;
+                }
+                if (pending[0].size() >= cfg_.batch_size || pending[1].size() >= cfg_.batch_size) wake = true;
+                if (ready.empty() && busy == 0) wake = true;
+                if (wake) cv_eval.notify_all();
             }
         };
         std::vector<std::thread> workers;
@@ -455,6 +486,10 @@ class SelfPlayRunner {
             for (auto& t : evals) t.join();
         }
         for (auto& t : workers) t.join();
+#ifdef CATTUS_SCHED_STATS
+        fprintf(stderr, "sched: workers %u  idle %.2fs  lock %.2fs  advance %.2fs  iterations %llu\n", cfg_.threads, st_wait * 1e-9,
+                st_lock * 1e-9, st_adv * 1e-9, (unsigned long long)st_iters.load());
+#endif
         for (auto& b : bufs) {
             hfree(b.planes), hfree(b.policy), hfree(b.value);
             if (b.legal_idx) hfree(b.legal_idx), hfree(b.legal_cnt);
@@ -464,6 +499,7 @@ class SelfPlayRunner {
         for (auto& s : slots)
             if (!s.error.empty()) error_ = s.error, frc = -2;
         res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (res.steady_seconds == 0) res.steady_seconds = res.seconds, res.steady_node_evals = metrics_.node_evals;
         return frc;
     }
 
@@ -518,6 +554,10 @@ class SelfPlayRunner {
                     }
                     s.game_idx = cfg_.first_game + local * cfg_.game_stride;
                     s.players_switch = s.game_idx % 2 == 1;
+                    // the random streams belong to the game, not to the slot that happens to play it: a game
+                    // is then the same whatever the schedule, the slot count or the sharding over processes
+                    s.p1.reseed(mix64(cfg_.seed * 1000003ull + s.game_idx) * 2 + 1);
+                    s.p2.reseed(mix64(cfg_.seed * 1000003ull + s.game_idx) * 2 + 2);
                     s.history.assign(1, Position::initial());
                     s.repetition_detected = false;
                     s.pairs.clear();

@@ -20,7 +20,8 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libcattus_selfplay.so"
+# CATTUS_SELFPLAY_LIB selects another build of the same ABI (e.g. one with -DCATTUS_SCHED_STATS)
+LIB_PATH = Path(os.environ.get("CATTUS_SELFPLAY_LIB", _PKG / "libcattus_selfplay.so"))
 
 GAMES = {"tictactoe": 0, "ttt": 0, "hex4": 1, "hex5": 2, "hex7": 3, "hex9": 4, "hex11": 5, "chess": 6}
 
@@ -95,6 +96,8 @@ class SpSummary(C.Structure):
         ("run_duration", C.c_double),
         ("search_duration", C.c_double),
         ("seconds", C.c_double),
+        ("steady_seconds", C.c_double),
+        ("steady_node_evals", C.c_uint64),
     ]
 
 

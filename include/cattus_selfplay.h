@@ -73,6 +73,10 @@ typedef struct cattus_sp_summary {
     uint64_t cache_hits, cache_misses;
     double run_duration, search_duration; /* reference EMA metrics model.run_duration, mcts.search_duration */
     double seconds;
+    /* the run up to the moment fewer than 3/4 of the concurrent-game slots still had a game to play,
+     * i.e. without the drain at the end when batches can no longer be filled */
+    double steady_seconds;
+    uint64_t steady_node_evals;
 } cattus_sp_summary;
 
 typedef struct cattus_sp_result cattus_sp_result;

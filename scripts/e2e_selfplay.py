@@ -31,7 +31,8 @@ with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="bf16") as ev:
     st = ev.stats()
 print(json.dumps(dict(
     threads=threads, slots=slots, sims=sims, games=games, diverse=diverse, device_softmax=devsoftmax, eval_threads=eval_threads, seconds=round(dt, 3),
-    node_evals=res["node_evals"], evals_per_s=round(res["node_evals"] / dt), batches=res["activation_count"],
+    node_evals=res["node_evals"], evals_per_s=round(res["node_evals"] / dt),
+    steady_evals_per_s=round(res["steady_node_evals"] / res["steady_seconds"]), steady_seconds=round(res["steady_seconds"], 2), batches=res["activation_count"],
     batch_fill=round(res["node_evals"] / max(1, res["activation_count"]), 1), positions=res["positions"],
     plies_per_game=round(res["positions"] / games, 1), games_per_hour=round(games * 3600 / dt),
     cache_hits=res["cache_hits"], gpu_busy_frac=round(st["run_seconds_total"] / dt, 3),

@@ -191,3 +191,24 @@ def test_legal_softmax_network_gives_the_same_games(game, moves):
     assert (a["record_bytes"] == b["record_bytes"]).all()
     assert a["node_evals"] == b["node_evals"] == seen["leaves"]
     assert seen["max_cnt"] <= moves
+
+
+def test_noisy_games_do_not_depend_on_schedule_or_sharding():
+    """With temperature sampling and Dirichlet noise on, the random streams are seeded per game (not per
+    slot or thread), so the same games come out of any schedule and any sharding."""
+    kw = dict(sim_num=20, temperature_policy=[(4, 1.0), (9999, 0.0)], prior_noise_alpha=0.3, prior_noise_epsilon=0.25, cache_size=10000)
+    ref = sp.run_self_play("hex5", _cfg(**kw), sp.Net.stub("hex5"), None, 12)
+    for extra in (dict(threads=4, batch_size=8, concurrent_games=5), dict(threads=3, batch_size=4, concurrent_games=12, eval_threads=1)):
+        got = sp.run_self_play("hex5", _cfg(**kw, **extra), sp.Net.stub("hex5"), None, 12)
+        assert (got["record_meta"] == ref["record_meta"]).all()
+        assert (got["record_bytes"] == ref["record_bytes"]).all()
+    parts = [sp.run_self_play("hex5", _cfg(**kw, threads=2, batch_size=4, first_game=r, game_stride=2), sp.Net.stub("hex5"), None, 6) for r in range(2)]
+    meta = np.concatenate([p["record_meta"] for p in parts])
+    rec = np.concatenate([p["record_bytes"] for p in parts])
+    order = np.lexsort((meta[:, 2], meta[:, 1], meta[:, 0]))
+    rorder = np.lexsort((ref["record_meta"][:, 2], ref["record_meta"][:, 1], ref["record_meta"][:, 0]))
+    assert (meta[order] == ref["record_meta"][rorder]).all()
+    assert (rec[order] == ref["record_bytes"][rorder]).all()
+    # and games differ from each other (the noise is really on)
+    firsts = {ref["record_bytes"][i].tobytes() for i in range(len(ref["record_bytes"])) if ref["record_meta"][i][1] == 1}
+    assert len(firsts) > 1
