@@ -152,7 +152,7 @@ struct ServerBatch {
     std::vector<float> policy, value;
 };
 
-constexpr int NLANES = 2;
+constexpr int NLANES = CATTUS_HIP_LANES;
 
 struct Lane {
     hipStream_t stream = nullptr;
@@ -708,9 +708,15 @@ CATTUS_API int cattus_hip_eval_legal(cattus_eval* e, const uint64_t* planes, uin
 
 CATTUS_API int cattus_hip_eval_device(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float* d_policy, float* d_value,
                                       void* stream) {
+    return cattus_hip_eval_device_lane(e, 0, d_planes, n, d_policy, d_value, stream);
+}
+
+CATTUS_API int cattus_hip_eval_device_lane(cattus_eval* e, uint32_t lane, const uint64_t* d_planes, uint32_t n, float* d_policy,
+                                           float* d_value, void* stream) {
     if (!e || !d_planes || !d_policy || !d_value) return fail(CATTUS_E_INVALID, "NULL argument");
     if (n < 1 || n > e->cfg.max_batch) return fail(CATTUS_E_INVALID, "invalid sample len %u, 1..=%u", n, e->cfg.max_batch);
-    Lane& L = e->lanes[0];
+    if (lane >= NLANES) return fail(CATTUS_E_INVALID, "lane %u out of range (%d lanes)", lane, NLANES);
+    Lane& L = e->lanes[lane];
     std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : L.stream;

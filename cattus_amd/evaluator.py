@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "cattus_hip_desc",
     "cattus_hip_eval",
     "cattus_hip_eval_device",
+    "cattus_hip_eval_device_lane",
     "cattus_hip_eval_legal",
     "cattus_hip_submit",
     "cattus_hip_wait",
@@ -100,6 +101,7 @@ def load_library():
     L.cattus_hip_desc.argtypes = [vp, C.POINTER(NetDescC)]
     L.cattus_hip_eval.argtypes = [vp, u64p, C.c_uint32, f32p, f32p]
     L.cattus_hip_eval_device.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+    L.cattus_hip_eval_device_lane.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp]
     u16p = C.POINTER(C.c_uint16)
     L.cattus_hip_eval_legal.argtypes = [vp, u64p, C.c_uint32, u16p, u16p, C.c_uint32, f32p, f32p]
     L.cattus_hip_submit.argtypes = [vp, u64p, C.POINTER(C.c_uint64)]
@@ -235,9 +237,9 @@ class HipEvaluator:
         policy, value = self.eval(planes)
         return [(policy[i], float(value[i])) for i in range(len(value))]
 
-    def eval_device(self, d_planes: int, n: int, d_policy: int, d_value: int, stream: int = 0):
+    def eval_device(self, d_planes: int, n: int, d_policy: int, d_value: int, stream: int = 0, lane: int = 0):
         """Asynchronous evaluation on raw device pointers (all buffers resident in HBM)."""
-        _check(self._lib.cattus_hip_eval_device(self._h, d_planes, n, d_policy, d_value, stream))
+        _check(self._lib.cattus_hip_eval_device_lane(self._h, lane, d_planes, n, d_policy, d_value, stream))
 
     # -- leaf server (Batcher::apply replacement, util/batch.rs:49-177) ---------------------
     def submit(self, planes_one) -> int:

@@ -91,6 +91,15 @@ int cattus_hip_eval_legal(cattus_eval* e, const uint64_t* planes, uint32_t n, co
 int cattus_hip_eval_device(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float* d_policy,
                            float* d_value, void* stream);
 
+/* The evaluator keeps CATTUS_HIP_LANES independent sets of activation buffers.  cattus_hip_eval and the
+ * leaf server pick a free one per call, so that many host threads can each have a batch in flight;
+ * cattus_hip_eval_device uses lane 0.  This variant names the lane: work enqueued on different lanes
+ * and different streams may overlap on the device (the tail of one batch's kernels with the head of
+ * the other's).  Two calls on the same lane must be ordered by the caller (same stream or events). */
+#define CATTUS_HIP_LANES 2
+int cattus_hip_eval_device_lane(cattus_eval* e, uint32_t lane, const uint64_t* d_planes, uint32_t n,
+                                float* d_policy, float* d_value, void* stream);
+
 /* Leaf-batching server, the replacement of Batcher::apply (engine/src/util/batch.rs:49-177):
  * submit copies one leaf's planes and returns a ticket; wait blocks until that leaf's batch ran
  * and copies its logits/value out.  A batch runs when max_batch leaves are queued, when the oldest
