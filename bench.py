@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="chess20x256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, choices=[1, 2], default=1,
+                    help="2 = also time the K steps with two batches in flight (extra object; `value` stays single-stream)")
     ap.add_argument("--selfplay-games", type=int, default=1024, help="games per GPU of the end-to-end self-play leg (0 = skip)")
     ap.add_argument("--selfplay-sims", type=int, default=64)
     args = ap.parse_args()
@@ -216,27 +218,31 @@ def main():
 
     # ---- the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
     # driver runs the evaluator: one batch's kernel tails overlap the other's heads.  Reported beside `value`.
-    side = torch.cuda.Stream(device=dev)
-    d_policy2, d_value2 = torch.empty_like(d_policy), torch.empty_like(d_value)
-    lanes = [(0, stream, d_policy, d_value), (1, side, d_policy2, d_value2)]
+    def time_two_lanes():
+        side = torch.cuda.Stream(device=dev)
+        d_policy2, d_value2 = torch.empty_like(d_policy), torch.empty_like(d_value)
+        lanes = [(0, stream, d_policy, d_value), (1, side, d_policy2, d_value2)]
 
-    def step2(i):
-        lane, st, pol, val = lanes[i & 1]
-        ev.eval_device(d_planes.data_ptr(), batch, pol.data_ptr(), val.data_ptr(), st.cuda_stream, lane=lane)
+        def step2(i):
+            lane, st, pol, val = lanes[i & 1]
+            ev.eval_device(d_planes.data_ptr(), batch, pol.data_ptr(), val.data_ptr(), st.cuda_stream, lane=lane)
 
-    for i in range(max(2, args.warmup // 2 * 2)):
-        step2(i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step2(i)
-    sync_all()
-    elapsed2 = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed2], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed2 = float(t.item())
-    assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
+        for i in range(max(2, args.warmup // 2 * 2)):
+            step2(i)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step2(i)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
+        return dt
+
+    elapsed2 = time_two_lanes() if args.lanes == 2 else None
 
     # ---- secondary measurement: end-to-end self-play games/hour (same network, real search on the host) ----
     sp_out = None
@@ -292,11 +298,6 @@ def main():
                 "flop_per_leaf": d.flops_per_position(),
             },
             "per_gpu_value": value / world,
-            "two_batches_in_flight": {
-                "value": batch * world * args.steps / elapsed2,
-                "ms_per_step": elapsed2 / args.steps * 1e3,
-                "note": "same K steps alternating between the evaluator's two lanes on two streams",
-            },
             "roofline": {
                 "kernel": "tower_persistent_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel",
                 "bound": "mfma",
@@ -316,6 +317,12 @@ def main():
             from cattus_amd import evaluator as ev_mod
 
             out["roofline_plane_pack"] = pack_roofline(torch, ev_mod.load_library(), dev, stream)
+        if elapsed2 is not None:
+            out["two_batches_in_flight"] = {
+                "value": batch * world * args.steps / elapsed2,
+                "ms_per_step": elapsed2 / args.steps * 1e3,
+                "note": "same K steps alternating between the evaluator's two lanes on two streams",
+            }
         if sp_out is not None:
             out["selfplay"] = sp_out
         if world == 1 and not args.no_cpu_baseline:

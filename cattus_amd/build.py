@@ -25,6 +25,10 @@ HIPCC_FLAGS = [
     "-shared",
     "-ffp-contract=off",
     "-fvisibility=hidden",
+    # kernel arguments arrive in SGPRs with the wave instead of through a dependent scalar load: the conv
+    # launches are short (17 us) and start cold, so the first-load latency matters (measured -0.5 us/launch)
+    "-mllvm",
+    "-amdgpu-kernarg-preload-count=16",
     "-Wall",
     "-Wno-unused-result",
 ]
