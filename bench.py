@@ -130,7 +130,11 @@ def selfplay_leg(ev_blob, d, dtype: str, local_rank: int, rank: int, world: int,
     from cattus_amd.evaluator import HipEvaluator
 
     threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
-    slots = 1024  # >= 4 batches of leaves in flight keeps the batches full while other slots search
+    # keep the leg near a minute whatever CPU share this rank has: a host thread sustains roughly 25 k
+    # simulations/s of chess search, the GPU roughly 350 k evaluations/s, a game costs about 200 * sims leaves
+    capacity = min(350e3, threads * 25e3)
+    games = int(min(games, max(64, 60.0 * capacity / (200.0 * sims)))) // 2 * 2
+    slots = min(1024, games)  # >= 4 batches of leaves in flight keeps the batches full while other slots search
     with HipEvaluator(ev_blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
         cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
                              temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25,
