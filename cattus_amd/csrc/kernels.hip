@@ -493,13 +493,22 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         issue_w(1);
         int pending = WPL;  // loads issued after the data of the upcoming step
         for (int t = 0; t < T_total; t++) {
-            {
-                STAMP_ACC_BEGIN;
-                if (pending == WPL + APL) wait_vm_barrier<WPL + APL>();
-                else if (pending == WPL) wait_vm_barrier<WPL>();
-                else wait_vm_barrier<0>();
-                STAMP_ACC_END(4);
+#ifdef CATTUS_STAMPS
+            {  // diagnostic build: time the wait for the data (slot 4) and the wait at the barrier (slot 7) apart
+                const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+                if (pending == WPL + APL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPL + APL) : "memory");
+                else if (pending == WPL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+                asm volatile("s_barrier" ::: "memory");
+                st_[4] += t1_ - t0_;
+                st_[7] += __builtin_amdgcn_s_memtime() - t1_;
             }
+#else
+            if (pending == WPL + APL) wait_vm_barrier<WPL + APL>();
+            else if (pending == WPL) wait_vm_barrier<WPL>();
+            else wait_vm_barrier<0>();
+#endif
             if (t == 0) STAMP(1);
             pending = 0;
             const int ch = t / 3, g = t - ch * 3;

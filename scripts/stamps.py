@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-os.environ["CATTUS_HIP_LIB"] = os.path.join(ROOT, "cattus_amd", "libcattus_hip_diag.so")
+os.environ.setdefault("CATTUS_HIP_LIB", os.path.join(ROOT, "cattus_amd", "libcattus_hip_diag.so"))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
@@ -34,7 +34,8 @@ clk = np.median(tot / np.maximum(rt, 1e-12)) / 1e9
 print(f"dtype {dtype}: in-kernel clock ~{clk:.2f} GHz; consumer wave lifetime median {np.median(tot):.0f} cycles = {np.median(tot)/clk/1e3:.2f} us")
 print(f"  consumers: prologue (start->first barrier passed) {np.median(cons[...,1]-cons[...,0]):.0f}, loop {np.median(cons[...,2]-cons[...,1]):.0f}, "
       f"epilogue {np.median(cons[...,3]-cons[...,2]):.0f}; of the loop, blocked at barriers {np.median(cons[...,4]):.0f}")
-print(f"  loaders  : lifetime {np.median(load[...,3]-load[...,0]):.0f}, blocked in vmcnt+barrier {np.median(load[...,4]):.0f}")
+print(f"  loaders  : lifetime {np.median(load[...,3]-load[...,0]):.0f}, waiting for data (vmcnt) {np.median(load[...,4]):.0f}, "
+      f"waiting at barriers {np.median(load[...,7]):.0f}; prologue {np.median(load[...,1]-load[...,0]):.0f}")
 mfma = {"bf16": 12 * 48 * 32, "f32": 24 * 192 * 64}[dtype]
 print(f"  MFMA-bound loop time {mfma} cycles -> loop efficiency {mfma/np.median(cons[...,2]-cons[...,1]):.2f}, kernel efficiency {mfma/np.median(tot):.2f}")
 skew = (cons[..., 3].max() - cons[..., 0].min())
