@@ -195,6 +195,7 @@ struct cattus_eval {
     std::atomic<bool> persistent{false};
     DevBuf tower_layers;
     uint32_t tower_out_buf = 1;  // index (1..3) of the buffer holding the tower output
+    bool tower_xcd_local = false;  // hand-off through one XCD's L2 (CATTUS_TOWER=persistent-xcd)
     std::mutex stat_mu;
     cattus_stats stats{};
 
@@ -356,7 +357,8 @@ int build(cattus_eval* e, const float* p) {
         // in-kernel hand-offs between the workgroups of a board group (measured +2 % on chess 20x256 at
         // batch 256; it needs those workgroups resident together and falls back on a time-out).
         const char* mode = getenv("CATTUS_TOWER");
-        e->persistent = mode && strcmp(mode, "persistent") == 0;
+        e->persistent = mode && (strcmp(mode, "persistent") == 0 || strcmp(mode, "persistent-xcd") == 0);
+        e->tower_xcd_local = mode && strcmp(mode, "persistent-xcd") == 0;
     }
     for (Lane& L : e->lanes) {
         HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
@@ -371,7 +373,7 @@ int build(cattus_eval* e, const float* p) {
         if ((rc = L.d_policy.alloc(B * d.moves * 4))) return rc;
         if ((rc = L.d_value.alloc(B * 4))) return rc;
         if (e->tuned) {
-            const size_t ncnt = ((size_t)(bp_ / BOARDS_PER_WG) * nlayers + 3) / 4 * 4;
+            const size_t ncnt = (size_t)(bp_ / BOARDS_PER_WG) * nlayers * 8;
             if ((rc = L.tower_counters.alloc(ncnt * 4))) return rc;
             if ((rc = L.tower_err.alloc(16))) return rc;
             HIP_TRY(hipMemset(L.tower_err.p, 0, 16));
@@ -410,7 +412,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         if (e->persistent) {
             // one launch for the whole tower; hand-off counters are re-zeroed by a memset node in front of it
             const uint32_t nlayers = 1 + 2 * d.blocks;
-            const size_t ncnt = ((size_t)(nb / BOARDS_PER_WG) * nlayers + 3) / 4 * 4;
+            const size_t ncnt = (size_t)(nb / BOARDS_PER_WG) * nlayers * 8;
             (void)hipMemsetAsync(L.tower_counters.p, 0, ncnt * 4, st);
             TowerArgs ta{};
             ta.buf[0] = L.x0.p, ta.buf[1] = L.a.p, ta.buf[2] = L.t.p, ta.buf[3] = L.y.p;
@@ -419,6 +421,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             ta.err = L.tower_err.as<unsigned>();
             ta.nlayers = (int)nlayers, ta.cout = (int)F, ta.S = (int)S;
             ta.spin_budget_ticks = 2000000;  // 20 ms
+            ta.xcd_local = e->tower_xcd_local ? 1 : 0;
             hipEvent_t s0 = ev(false), s1 = ev(true);
             launch_tower_persistent(e->act, ta, nb, st, s0, s1);
             a = ta.buf[e->tower_out_buf];

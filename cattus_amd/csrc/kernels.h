@@ -42,9 +42,10 @@ struct TowerLayer {
 struct TowerArgs {
     void* buf[4];              // 0: stem input [B4][64][cin0], 1..3: tower ping-pong buffers [B4][64][cout]
     const TowerLayer* layers;  // device array [nlayers]
-    unsigned* counters;        // [board groups][nlayers], zeroed before every launch
+    unsigned* counters;        // [board groups][nlayers][8], zeroed before every launch
     unsigned* err;             // set to 1 if a wait timed out
     int nlayers, cout, S;
+    int xcd_local;             // 1: hand-off through the shared L2 of one XCD (see kernels.hip), 0: agent scope
     long long spin_budget_ticks;  // s_memrealtime ticks (100 MHz)
 };
 void launch_tower_persistent(Act act, const TowerArgs& args, uint32_t bpad, hipStream_t st, hipEvent_t ev_start = nullptr,

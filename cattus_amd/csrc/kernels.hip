@@ -203,6 +203,10 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
 }
+// the same with sc1: bypasses this CU's L1 and is served by the XCD's L2
+__device__ __forceinline__ void glds16_l2(const char* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 16);
+}
 
 template <typename T, bool HAS_RES>
 __global__ void __launch_bounds__(256, 1)
@@ -728,6 +732,15 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 //   consumer: one lane polls the counter (relaxed agent loads, s_sleep between polls, bounded by a
 //             wall-clock budget); then one agent-scope acquire (invalidates this CU's L1), drained;
 //             workgroup barrier; only then are the activations requested.
+// Same-XCD variant (TowerArgs::xcd_local): the workgroups of a board group have equal blockIdx % 8, which the
+// dispatcher is observed to place on one XCD, i.e. behind one L2.  Then nothing has to leave that L2:
+//   producer: plain stores (the lines stay in the XCD's L2), drained; barrier; one lane adds 1 with a
+//             non-sc1 atomic (executed in that L2) to the counter slot of ITS OWN XCC id (HW_REG_XCC_ID).
+//   consumer: polls the slot of its own XCC id with L1-bypassing loads; no L1 invalidate: the activation
+//             DMA and the skip-row loads of this kernel carry sc1 (bypass L1, served by the L2).
+// If the dispatcher ever placed a group's workgroups on different XCDs their adds would land in different
+// slots, the consumer's slot would never fill, the wait would time out and the host falls back: placement
+// decides speed, a wrong assumption about it costs one time-out, never a wrong result.
 // Correctness never depends on placement.  Progress needs the workgroups of one board group to be
 // resident together: 139 KB of LDS admits one workgroup per CU and they are dispatched in blockIdx
 // order, so the first 256 blocks always contain whole groups.  Every spin is bounded: on time-out the
@@ -750,6 +763,9 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persi
     const int cout0 = (logical % ncb) * COUT_PER_WG;
     const int bg = logical / ncb;
     const int b0 = bg * BOARDS_PER_WG;
+    const bool xl = A.xcd_local != 0;
+    // counter slot: this CU's XCC id (HW_REG_XCC_ID = 20, bits 3:0) in the same-XCD protocol, else slot 0
+    const unsigned slot = xl ? (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) : 0u;
 
     if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -820,8 +836,13 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persi
             auto issue_a = [&](int ch, int g) {
                 const char* src = abase0 + (size_t)ch * 128;
                 char* dst = smem + V2_LDS_ACT + (ch & 1) * 32768;
+                if (xl) {
 #pragma unroll
-                for (int i = 0; i < APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
+                    for (int i = 0; i < APL; i++) glds16_l2(src + off_a[g][i], dst + dst_a[g][i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
+                }
             };
 
             // weights do not depend on the other workgroups: request them while the hand-off completes
@@ -853,7 +874,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persi
         // ================================ consumer waves ================================
         if (layer > 0 && wave == 0) {
             // wait until every workgroup of this board group has published the previous layer
-            unsigned* cnt = A.counters + (size_t)bg * A.nlayers + (layer - 1);
+            unsigned* cnt = A.counters + ((size_t)bg * A.nlayers + (layer - 1)) * 8 + slot;
             if (lane == 0) {
                 const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ncb) {
@@ -864,8 +885,10 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persi
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!xl) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier A
 
@@ -930,15 +953,21 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persi
             const size_t board = (size_t)(b0 + wave);
             const int tile0 = V2_LDS_ACT + wave * 8192;
             const int prow = lane >> 3, cg = lane & 7;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            const size_t act_bytes_total = (size_t)(gridDim.x / ncb) * BOARDS_PER_WG * SLOTS * cout * sizeof(T);
+            auto rsrc_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(res), 0, (int)act_bytes_total, 0x00020000);
             auto load_res = [&](int i0, T (&rv)[4][8]) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const size_t off = (board * SLOTS + (i0 + i) * 8 + prow) * (size_t)cout + cout0 + cg * 8;
-                    if (sizeof(T) == 2) {
-                        *reinterpret_cast<f32x4*>(rv[i]) = *reinterpret_cast<const f32x4*>(res + off);
+                    const unsigned boff = (unsigned)(off * sizeof(T));
+                    u32x4* dst = reinterpret_cast<u32x4*>(rv[i]);
+                    if (xl) {  // sc1: not from this CU's L1, which nothing has invalidated
+                        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff, 0, 16);
+                        if (sizeof(T) == 4) dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff + 16, 0, 16);
                     } else {
-                        reinterpret_cast<f32x4*>(rv[i])[0] = reinterpret_cast<const f32x4*>(res + off)[0];
-                        reinterpret_cast<f32x4*>(rv[i])[1] = reinterpret_cast<const f32x4*>(res + off)[1];
+                        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff, 0, 0);
+                        if (sizeof(T) == 4) dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff + 16, 0, 0);
                     }
                 }
             };
@@ -959,9 +988,8 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persi
                         const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
                         *reinterpret_cast<f32x4*>(smem + tile0 + pb * 32768 + r * 256 + slot * 16) = v;
                     }
-            // buffer descriptor for the write-through stores (aux 16 = sc1)
-            const size_t out_bytes = (size_t)(gridDim.x / ncb) * BOARDS_PER_WG * SLOTS * cout * sizeof(T);
-            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
+            // buffer descriptor for the output stores (aux 16 = sc1 = write-through)
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)act_bytes_total, 0x00020000);
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 if (half == 1 && has_res) load_res(4, resv);
@@ -986,21 +1014,24 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persi
                         if (!valid) y = 0.0f;
                         ov[j] = (T)y;
                     }
-                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
                     const unsigned boff = (unsigned)(off * sizeof(T));
-                    if (sizeof(T) == 2) {
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4*>(ov), rsrc, boff, 0, 16);
+                    if (xl) {  // plain: the line stays in this XCD's L2 for the next layer's readers
+                        __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[0], rsrc, boff, 0, 0);
+                        if (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[1], rsrc, boff + 16, 0, 0);
                     } else {
                         __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[0], rsrc, boff, 0, 16);
-                        __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[1], rsrc, boff + 16, 0, 16);
+                        if (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[1], rsrc, boff + 16, 0, 16);
                     }
                 }
             }
         }
         // publish: every storing wave drains its write-through stores, the workgroup meets, one lane signals
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier P
-        if (wave == 0 && lane == 0)
-            __hip_atomic_fetch_add(A.counters + (size_t)bg * A.nlayers + layer, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0 && lane == 0) {
+            unsigned* cnt = A.counters + ((size_t)bg * A.nlayers + layer) * 8 + slot;
+            if (xl) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // in this XCD's L2
+            else __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -203,8 +203,10 @@ def test_full_size_chess_20x256_batch_256():
     assert agree >= 0.9, agree
 
 
-def test_persistent_tower_equals_per_layer_launches(monkeypatch):
-    """CATTUS_TOWER=persistent runs the whole tower in one launch with workgroup-to-workgroup hand-offs;
+@pytest.mark.parametrize("mode", ["persistent", "persistent-xcd"])
+def test_persistent_tower_equals_per_layer_launches(monkeypatch, mode):
+    """CATTUS_TOWER=persistent runs the whole tower in one launch with workgroup-to-workgroup hand-offs
+    (agent-scope release/acquire; `persistent-xcd`: through the shared L2 of one XCD, checked by XCC id);
     results must be bit-identical to the per-layer kernels in both dtypes."""
     d = NetDesc(**CHESS, blocks=6, filters=256, vhc=8, phc=8)
     blob = seeded_blob(d, 11)
@@ -213,11 +215,14 @@ def test_persistent_tower_equals_per_layer_launches(monkeypatch):
         monkeypatch.delenv("CATTUS_TOWER", raising=False)
         with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype) as ev:
             p0, v0 = ev.eval(planes)
-        monkeypatch.setenv("CATTUS_TOWER", "persistent")
+        monkeypatch.setenv("CATTUS_TOWER", mode)
         with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype) as ev:
-            for n in (256, 37, 4):
+            for n in (256, 37, 4, 256, 255):
                 p1, v1 = ev.eval(planes[:n])
                 assert (p1 == p0[:n]).all() and (v1 == v0[:n]).all()
+            for _ in range(20):  # repeated passes reuse the ping-pong buffers: stale cache lines would show
+                p1, v1 = ev.eval(planes)
+                assert (p1 == p0).all() and (v1 == v0).all()
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
