@@ -458,8 +458,8 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         hd.w1 = e->w1t.p, hd.b1 = e->b1.as<float>(), hd.h1 = L.h1.as<float>();
         hd.wp = e->wpt.p, hd.bp = e->bp.as<float>(), hd.policy = d_policy;
         hd.hw = hw, hd.vhc = d.vhc, hd.phc = d.phc, hd.kvp = e->kvp, hd.kpp = e->kpp, hd.M = d.moves;
+        hd.w2 = e->w2.as<float>(), hd.b2 = e->b2.as<float>(), hd.value = d_value;
         launch_heads_mfma(e->act, a, n, F, hd, st);
-        launch_value_fc2_tanh(L.h1.as<float>(), e->w2.as<float>(), e->b2.as<float>(), n, d_value, st);
     } else {
         TowerView tv;
         tv.x = a, tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;

@@ -75,6 +75,8 @@ struct HeadsMfma {
     const void* wp;
     const float* bp;
     float* policy;
+    const float *w2, *b2;  // value FC2 [128], [1]
+    float* value;          // [nb], tanh applied
     uint32_t hw, vhc, phc, kvp, kpp, M;
 };
 void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, const HeadsMfma& hd, hipStream_t st);

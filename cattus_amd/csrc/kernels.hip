@@ -1175,14 +1175,14 @@ struct HeadEpi {
 };
 
 template <typename T, int EPI>
-__global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P, uint32_t ldp, uint32_t I,
-                                                        const T* __restrict__ Q, uint32_t ldq, uint32_t J, uint32_t K,
-                                                        HeadEpi ep) {
+__device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t ldp, uint32_t I, const T* __restrict__ Q,
+                                               uint32_t ldq, uint32_t J, uint32_t K, const HeadEpi& ep, uint32_t bx,
+                                               uint32_t by, float* stage = nullptr) {
     typedef typename Mfma<T>::frag frag;
     constexpr uint32_t KSTEP = 32 / sizeof(T);  // k per MFMA stage: 16 (bf16) or 8 (f32)
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
-    const uint32_t i0 = blockIdx.y * 32, j0 = (blockIdx.x * 4 + wave) * 32;
+    const uint32_t i0 = by * 32, j0 = (bx * 4 + wave) * 32;
     if (j0 >= J) return;
     const uint32_t pi = min(i0 + r, I - 1), qj = min(j0 + r, J - 1);
     const T* pp = P + (size_t)pi * ldp + h * (KSTEP / 2);
@@ -1221,6 +1221,7 @@ __global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P,
         } else if constexpr (EPI == EPI_FC1) {
             const float y = acc[e] + ep.bias[j];
             reinterpret_cast<float*>(ep.out)[(size_t)i * 128 + j] = y > 0.0f ? y : 0.0f;
+            if (stage) stage[(i - i0) * 129 + j] = y > 0.0f ? y : 0.0f;  // [32 leaves][128 hidden], padded rows
         } else {
             float y = acc[e] + ep.bias[j];
             // non-finite logits -> f32::MIN (reference: engine/src/net/mod.rs:56-61)
@@ -1228,6 +1229,45 @@ __global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P,
             reinterpret_cast<float*>(ep.out)[(size_t)i * ep.M + j] = y;
         }
     }
+}
+
+template <typename T, int EPI>
+__global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P, uint32_t ldp, uint32_t I,
+                                                        const T* __restrict__ Q, uint32_t ldq, uint32_t J, uint32_t K,
+                                                        HeadEpi ep) {
+    head_gemm_tile<T, EPI>(P, ldp, I, Q, ldq, J, K, ep, blockIdx.x, blockIdx.y);
+}
+
+// Value FC1 and policy FC read the same head activations and do not depend on each other: one launch,
+// the first `fc1_blocks` block columns do FC1, the rest the policy FC (same tile code, same arithmetic).
+struct HeadFcPair {
+    const void *p1, *q1, *p2, *q2;
+    uint32_t ldp, I, ldq1, J1, K1, ldq2, J2, K2, fc1_blocks;
+    HeadEpi ep1, ep2;
+    const float *w2, *b2;
+    float* value;
+};
+__device__ __forceinline__ float tanh_exact(float x);
+template <typename T>
+__global__ void __launch_bounds__(256) head_fc_pair_kernel(HeadFcPair a) {
+    if (blockIdx.x < a.fc1_blocks) {
+        // The block's four waves hold all 128 hidden units of 32 leaves: stage them in LDS and finish the
+        // value head here (FC2 + tanh, the fmaf chain of value_fc2_tanh_kernel), saving a launch.
+        __shared__ float h1s[32 * 129];
+        head_gemm_tile<T, EPI_FC1>((const T*)a.p1, a.ldp, a.I, (const T*)a.q1, a.ldq1, a.J1, a.K1, a.ep1, blockIdx.x, blockIdx.y, h1s);
+        __syncthreads();
+        const uint32_t leaf = blockIdx.y * 32 + threadIdx.x;
+        if (threadIdx.x < 32 && leaf < a.I) {
+            float acc = 0.0f;
+            for (uint32_t kk = 0; kk < 128; kk++) {
+                const uint32_t j = kperm(kk);
+                acc = __builtin_fmaf(a.w2[j], h1s[threadIdx.x * 129 + j], acc);
+            }
+            a.value[leaf] = tanh_exact(acc + a.b2[0]);
+        }
+    } else
+        head_gemm_tile<T, EPI_POLICY>((const T*)a.p2, a.ldp, a.I, (const T*)a.q2, a.ldq2, a.J2, a.K2, a.ep2,
+                                      blockIdx.x - a.fc1_blocks, blockIdx.y);
 }
 
 template <int EPI>
@@ -1249,14 +1289,21 @@ void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, cons
     // K3: both 1x1 convs in one GEMM: i = head channel, j = tower row
     ep.bias = hd.conv_b, ep.out = hd.hv;
     launch_head_gemm<EPI_HEADCONV>(act, hd.conv_w, F, 32, tower, F, nb * SLOTS, F, ep, st);
-    // K4: value FC1 (+ReLU): i = leaf, j = hidden unit
+    // K4 + K5 in one launch: value FC1 (+ReLU): i = leaf, j = hidden unit; policy FC: i = leaf, j = move
     const size_t esz = act == Act::BF16 ? 2 : 4;
-    ep.bias = hd.b1, ep.out = hd.h1;
-    launch_head_gemm<EPI_FC1>(act, hd.hv, ep.hvs, nb, hd.w1, hd.kvp, 128, hd.kvp, ep, st);
-    // K5: policy FC: i = leaf, j = move
-    ep.bias = hd.bp, ep.out = hd.policy;
-    launch_head_gemm<EPI_POLICY>(act, (const char*)hd.hv + (size_t)hd.kvp * esz, ep.hvs, nb, hd.wp, hd.kpp, hd.M, hd.kpp, ep,
-                                 st);
+    if (!nb) return;
+    HeadFcPair a{};
+    a.p1 = hd.hv, a.q1 = hd.w1, a.p2 = (const char*)hd.hv + (size_t)hd.kvp * esz, a.q2 = hd.wp;
+    a.ldp = ep.hvs, a.I = nb;
+    a.ldq1 = hd.kvp, a.J1 = 128, a.K1 = hd.kvp;
+    a.ldq2 = hd.kpp, a.J2 = hd.M, a.K2 = hd.kpp;
+    a.fc1_blocks = (128 / 32 + 3) / 4;
+    a.ep1 = ep, a.ep1.bias = hd.b1, a.ep1.out = hd.h1;
+    a.ep2 = ep, a.ep2.bias = hd.bp, a.ep2.out = hd.policy;
+    a.w2 = hd.w2, a.b2 = hd.b2, a.value = hd.value;
+    const dim3 grid(a.fc1_blocks + ((hd.M + 31) / 32 + 3) / 4, (nb + 31) / 32), block(256);
+    if (act == Act::BF16) hipLaunchKernelGGL(head_fc_pair_kernel<__bf16>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(head_fc_pair_kernel<float>, grid, block, 0, st, a);
 }
 
 // ---- SIMT path (generic tower layout, any shape), same term order ---------------------------
