@@ -51,6 +51,7 @@ SelfPlayConfig to_config(const cattus_sp_config* c) {
     cfg.host_alloc = c->host_alloc;
     cfg.host_free = c->host_free;
     cfg.eval_threads = c->eval_threads ? std::min(c->eval_threads, 8u) : 2;
+    cfg.mcts.leaves_in_flight = std::max(1u, std::min(c->leaves_in_flight, 16u));
     return cfg;
 }
 
@@ -293,7 +294,8 @@ SP_API int64_t cattus_sp_trace_game(int game, const cattus_sp_config* c, cattus_
     int64_t written = -1;
     dispatch(game, [&](auto g) -> int {
         typedef decltype(g) G;
-        const SelfPlayConfig cfg = to_config(c);
+        SelfPlayConfig cfg = to_config(c);
+        cfg.mcts.leaves_in_flight = 1;  // the trace is the sequential search, one evaluation at a time
         Metrics metrics;
         NetValueFunction<G> vf(NetHandle{net, ctx}, cfg.cache_size, &metrics);
         // exactly what one reference worker does for game 0: two persistent players (self_play.rs:180-217)

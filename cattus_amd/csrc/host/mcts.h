@@ -75,6 +75,10 @@ struct MctsParams {  // mcts/mod.rs:72-79
     float explore_factor = 1.41421356f;
     TemperaturePolicy temperature;
     float prior_noise_alpha = 0.0f, prior_noise_epsilon = 0.0f;
+    // Not in the reference (its search is strictly sequential): up to this many unexpanded leaves of ONE
+    // tree may wait for the network together, each holding a virtual loss on its path so that the next
+    // selection goes elsewhere.  1 = the reference's search, simulation by simulation.
+    uint32_t leaves_in_flight = 1;
 };
 
 template <typename G>
@@ -119,39 +123,58 @@ class MctsPlayer {
         assert(position == nodes_[root_].pos);
         index_history(history);
         sims_done_ = 0;
-        waiting_ = false;
+        inflight_n_ = delivered_ = 0;
     }
 
-    // develop_tree (mcts/mod.rs:156-196), suspended at the evaluation of an unexpanded leaf.
+    // develop_tree (mcts/mod.rs:156-196), suspended at the evaluation of unexpanded leaves.  Returns
+    // NEED_EVAL with pending_count() leaves to evaluate (always 1 unless leaves_in_flight > 1); the caller
+    // delivers every one of them before calling advance() again.
+    static constexpr uint32_t MAX_IN_FLIGHT = 16;
     Step advance(const std::vector<Position>& history) {
-        assert(!waiting_);
-        while (sims_done_ < params_.sim_num) {
-            select(path_);
-            const bool repetition = detect_repetition(path_);
-            leaf_ = path_.empty() ? root_ : edges_[path_.back()].target;
-            const Status st = nodes_[leaf_].status();
+        (void)history;
+        assert(inflight_n_ == 0);
+        const uint32_t K = std::min(std::max(params_.leaves_in_flight, 1u), MAX_IN_FLIGHT);
+        while (sims_done_ + inflight_n_ < params_.sim_num && inflight_n_ < K) {
+            InFlight& f = inflight_[inflight_n_];
+            select(f.path);
+            const uint32_t leaf = f.path.empty() ? root_ : edges_[f.path.back()].target;
+            if (nodes_[leaf].pending) break;  // selection ran into a leaf already waiting: evaluate what we have
+            const bool repetition = detect_repetition(f.path);
+            const Status st = nodes_[leaf].status();
             if (repetition) {
-                backpropagate(path_, 0.0f);
+                backpropagate(f.path, 0.0f);
+                sims_done_++;
             } else if (st.finished) {
-                backpropagate(path_, (float)st.winner);
+                backpropagate(f.path, (float)st.winner);
+                sims_done_++;
             } else {
-                waiting_ = true;
-                return NEED_EVAL;
+                f.leaf = leaf;
+                nodes_[leaf].pending = 1;
+                if (K > 1)
+                    for (uint32_t e : f.path) edges_[e].vl++;
+                inflight_n_++;
             }
-            sims_done_++;
         }
-        return SEARCH_DONE;
+        delivered_ = 0;
+        return inflight_n_ ? NEED_EVAL : SEARCH_DONE;
     }
-    const Position& pending_position() const { return nodes_[leaf_].pos; }
+    uint32_t pending_count() const { return inflight_n_; }
+    const Position& pending_position(uint32_t i = 0) const { return nodes_[inflight_[i].leaf].pos; }
 
     // second half of a simulation: create_children, root noise, backpropagate (mcts/mod.rs:179-194)
-    void deliver(const Evaluation<G>& ev) {
-        assert(waiting_);
-        create_children(leaf_, ev.probs);
-        if (leaf_ == root_) add_dirichlet_noise(root_);
-        backpropagate(path_, ev.value);
+    void deliver(const Evaluation<G>& ev) { deliver(0, ev); }
+    void deliver(uint32_t i, const Evaluation<G>& ev) {
+        assert(i < inflight_n_);
+        const InFlight& f = inflight_[i];
+        if (nodes_[f.leaf].pending == 0) return;  // already delivered
+        nodes_[f.leaf].pending = 0;
+        for (uint32_t e : f.path)
+            if (edges_[e].vl) edges_[e].vl--;
+        create_children(f.leaf, ev.probs);
+        if (f.leaf == root_) add_dirichlet_noise(root_);
+        backpropagate(f.path, ev.value);
         sims_done_++;
-        waiting_ = false;
+        if (++delivered_ == inflight_n_) inflight_n_ = 0;
     }
 
     // calc_moves_probabilities, second half (mcts/mod.rs:363-379): (move, n / sum n) in edges() order
@@ -208,7 +231,7 @@ class MctsPlayer {
         nodes_.clear();
         edges_.clear();
         has_root_ = false;
-        waiting_ = false;
+        inflight_n_ = delivered_ = 0;
     }
     size_t tree_nodes() const { return nodes_.size(); }
 
@@ -219,6 +242,7 @@ class MctsPlayer {
         // Position::status() memoised on first use: the reference re-derives it on every visit
         // (mcts/mod.rs:207), which for chess means a move generation per visited node per simulation.
         mutable int8_t st_known = 0, st_finished = 0, st_winner = 0;
+        uint8_t pending = 0;  // an evaluation of this (unexpanded) node is in flight
         Node(const Position& p, uint32_t f, uint32_t c) : pos(p), first(f), count(c) {}
         Status status() const {
             if (!st_known) {
@@ -234,12 +258,16 @@ class MctsPlayer {
         uint32_t n;
         float w;
         uint32_t source, target;
+        uint32_t vl = 0;  // virtual losses: in-flight simulations through this edge (0 in the reference's search)
     };
 
     // calc_selection_heuristic (mcts/mod.rs:233-244), f32 throughout
     float heuristic(const Edge& e, uint32_t parent_simcount) const {
-        const float exploit = e.n == 0 ? 0.0f : e.w / (float)e.n;
-        const float explore = params_.explore_factor * e.init_score * (std::sqrt((float)parent_simcount) / (float)(1 + e.n));
+        // an in-flight simulation counts as a visit that lost; with vl == 0 this is the reference's formula
+        const uint32_t n = e.n + e.vl;
+        const float w = e.vl ? e.w - (float)e.vl : e.w;
+        const float exploit = n == 0 ? 0.0f : w / (float)n;
+        const float explore = params_.explore_factor * e.init_score * (std::sqrt((float)parent_simcount) / (float)(1 + n));
         return exploit + explore;
     }
 
@@ -250,7 +278,7 @@ class MctsPlayer {
             const Node& node = nodes_[node_id];
             if (node.count == 0 || node.status().finished) return;
             uint32_t simcount = 1;
-            for (uint32_t i = 0; i < node.count; i++) simcount += edges_[node.first + i].n;
+            for (uint32_t i = 0; i < node.count; i++) simcount += edges_[node.first + i].n + edges_[node.first + i].vl;
             // edges() order = newest first; max_by keeps y unless cmp(best, y) == Greater
             uint32_t best = node.first + node.count - 1;
             float vbest = heuristic(edges_[best], simcount);
@@ -396,9 +424,13 @@ class MctsPlayer {
     bool has_root_ = false;
 
     // suspended-simulation state
-    uint32_t sims_done_ = 0, leaf_ = 0;
-    bool waiting_ = false;
-    std::vector<uint32_t> path_;
+    uint32_t sims_done_ = 0;
+    struct InFlight {
+        std::vector<uint32_t> path;
+        uint32_t leaf = 0;
+    };
+    InFlight inflight_[MAX_IN_FLIGHT];
+    uint32_t inflight_n_ = 0, delivered_ = 0;
     struct HistEntry {
         uint64_t hash;
         const Position* pos;  // into the caller's history vector, which outlives the search

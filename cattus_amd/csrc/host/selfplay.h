@@ -252,6 +252,7 @@ struct SelfPlayConfig {
     size_t cache_size = 1000;       // mcts.cache_size
     uint32_t concurrent_games = 0;  // slots; 0 -> max(threads, batch_size)
     uint32_t eval_threads = 2;      // threads calling the network (batches in flight)
+    // mcts.leaves_in_flight > 1 (not in the reference) lets one tree keep several leaves at the network
     uint64_t seed = 1;
     // this process plays global game indices first_game + k*game_stride, k = 0..games_num-1
     uint32_t first_game = 0, game_stride = 1;
@@ -377,10 +378,16 @@ class SelfPlayRunner {
                 while (k < take && !ready.empty()) mine[k++] = ready.front(), ready.pop_front();
                 busy += (uint32_t)k;
                 lk.unlock();
-                int released[CHUNK];
+                // batch buffers whose rows the slots consume in this round (a slot with several leaves in flight
+                // may hold rows of more than one buffer)
+                int released[CHUNK][MctsPlayer<G>::MAX_IN_FLIGHT];
+                uint32_t nrel[CHUNK];
                 for (size_t i = 0; i < k; i++) {
                     Slot& sl = slots[mine[i]];
-                    released[i] = sl.state == Slot::HAVE_RESULT ? sl.batch : -1;
+                    nrel[i] = 0;
+                    if (sl.state == Slot::HAVE_RESULT)
+                        for (uint32_t q = 0; q < sl.npend; q++)
+                            if (!sl.leaf[q].cached) released[i][nrel[i]++] = sl.leaf[q].batch;
                     advance(sl, next_game, games_num, out_dir1, out_dir2, records, res, out_mu);
                 }
                 SCHED_T(a1);
@@ -395,9 +402,14 @@ class SelfPlayRunner {
                 bool wake = false;  // something an evaluation thread may be waiting for has happened
                 for (size_t i = 0; i < k; i++) {
                     Slot& sl = slots[mine[i]];
-                    if (released[i] >= 0 && --bufs[released[i]].refs == 0) wake = true;
-                    if (sl.state == Slot::WAIT_EVAL) pending[sl.netid].push_back(mine[i]);
-                    else done++, wake = true;
+                    for (uint32_t q = 0; q < nrel[i]; q++)
+                        if (--bufs[released[i][q]].refs == 0) wake = true;
+                    if (sl.state == Slot::WAIT_EVAL) {
+                        for (uint32_t q = 0; q < sl.npend; q++)
+                            if (!sl.leaf[q].cached) pending[sl.netid].push_back(mine[i] * MctsPlayer<G>::MAX_IN_FLIGHT + q);
+                    } else {
+                        done++, wake = true;
+                    }
                 }
                 if (res.steady_seconds == 0 && (uint64_t)(nslots - done) * 4 < (uint64_t)nslots * 3) {
                     res.steady_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -440,7 +452,8 @@ class SelfPlayRunner {
                 lk.unlock();
                 int erc = 0;
                 for (size_t k = 0; k < n; k++) {
-                    const PendingLeaf<G>& pl = slots[who[k]].pend;
+                    constexpr uint32_t MIF = MctsPlayer<G>::MAX_IN_FLIGHT;
+                    const PendingLeaf<G>& pl = slots[who[k] / MIF].pend[who[k] % MIF];
                     memcpy(bb.planes + k * words, pl.planes, words * 8);
                     if (legal) {
                         if (pl.legal_count > LEGAL_STRIDE) erc = -5;
@@ -458,11 +471,11 @@ class SelfPlayRunner {
                     metrics_.activation_count++;  // counts batches, as the reference does (net/mod.rs:68)
                     metrics_.node_evals += n;
                     for (size_t k = 0; k < n; k++) {
-                        Slot& sl = slots[who[k]];
-                        sl.logits = bb.policy + k * row;
-                        sl.value = bb.value[k];
-                        sl.batch = bi;
-                        sl.state = Slot::HAVE_RESULT;
+                        constexpr uint32_t MIF = MctsPlayer<G>::MAX_IN_FLIGHT;
+                        auto& lf = slots[who[k] / MIF].leaf[who[k] % MIF];
+                        lf.logits = bb.policy + k * row;
+                        lf.value = bb.value[k];
+                        lf.batch = bi;
                     }
                 }
                 lk.lock();
@@ -472,7 +485,13 @@ class SelfPlayRunner {
                     rc = erc;
                     break;
                 }
-                for (size_t k = 0; k < n; k++) ready.push_back(who[k]);
+                for (size_t k = 0; k < n; k++) {  // a slot is ready again once all its leaves are back
+                    Slot& sl = slots[who[k] / MctsPlayer<G>::MAX_IN_FLIGHT];
+                    if (--sl.awaiting == 0) {
+                        sl.state = Slot::HAVE_RESULT;
+                        ready.push_back(who[k] / MctsPlayer<G>::MAX_IN_FLIGHT);
+                    }
+                }
                 cv_work.notify_all();
             }
             finished = true;
@@ -515,10 +534,17 @@ class SelfPlayRunner {
         std::vector<Position> history;
         bool repetition_detected = false;
         std::vector<std::pair<Position, std::vector<std::pair<Move, float>>>> pairs;
-        PendingLeaf<G> pend;
-        const float* logits = nullptr;  // row (logits, or legal-move probabilities) of batch buffer `batch` until consumed
-        int batch = -1;
-        float value = 0;
+        // leaves of the current search waiting for an evaluation (one, unless mcts.leaves_in_flight > 1)
+        PendingLeaf<G> pend[MctsPlayer<G>::MAX_IN_FLIGHT];
+        struct LeafResult {
+            bool cached = false;            // served from the evaluation cache: `ev` holds the result
+            Evaluation<G> ev;
+            const float* logits = nullptr;  // else: row (logits, or legal-move probabilities) of batch buffer `batch`
+            float value = 0;
+            int batch = -1;
+        } leaf[MctsPlayer<G>::MAX_IN_FLIGHT];
+        uint32_t npend = 0;     // leaves of the current group
+        uint32_t awaiting = 0;  // of them, still at the network (guarded by the scheduler mutex)
         std::chrono::steady_clock::time_point search_t0;
         std::string error;
         Slot(const MctsParams& p, uint64_t seed) : p1(p, seed * 2 + 1), p2(p, seed * 2 + 2) {}
@@ -581,22 +607,39 @@ class SelfPlayRunner {
                     break;
                 }
                 case Slot::HAVE_RESULT: {
-                    Evaluation<G> ev;
+                    // every leaf of the group is resolved: deliver them in index order, whatever order they
+                    // came back in, so that the tree does not depend on timing
                     auto& vf = s.netid == 0 ? vf1_ : vf2_;
-                    if (vf.net().legal_fn) vf.finish_legal(s.pend, s.logits, s.value, ev);
-                    else vf.finish(s.pend, s.logits, s.value, ev);
-                    s.cur->deliver(ev);
-                    s.logits = nullptr;  // the caller releases the batch buffer reference
+                    for (uint32_t q = 0; q < s.npend; q++) {
+                        if (s.leaf[q].cached) {
+                            s.cur->deliver(q, s.leaf[q].ev);
+                            continue;
+                        }
+                        Evaluation<G> ev;
+                        if (vf.net().legal_fn) vf.finish_legal(s.pend[q], s.leaf[q].logits, s.leaf[q].value, ev);
+                        else vf.finish(s.pend[q], s.leaf[q].logits, s.leaf[q].value, ev);
+                        s.cur->deliver(q, ev);
+                        s.leaf[q].logits = nullptr;  // the caller releases the batch buffer reference
+                    }
+                    s.npend = 0;
                     s.state = Slot::SEARCHING;
                     break;
                 }
                 case Slot::SEARCHING: {
                     const auto step = s.cur->advance(s.history);
                     if (step == MctsPlayer<G>::NEED_EVAL) {
-                        Evaluation<G> ev;
-                        if ((s.netid == 0 ? vf1_ : vf2_).prepare(s.cur->pending_position(), s.pend, ev)) {
-                            s.cur->deliver(ev);
+                        auto& vf = s.netid == 0 ? vf1_ : vf2_;
+                        s.npend = s.cur->pending_count();
+                        uint32_t to_net = 0;
+                        for (uint32_t q = 0; q < s.npend; q++) {
+                            s.leaf[q].cached = vf.prepare(s.cur->pending_position(q), s.pend[q], s.leaf[q].ev);
+                            if (!s.leaf[q].cached) to_net++;
+                        }
+                        if (to_net == 0) {
+                            for (uint32_t q = 0; q < s.npend; q++) s.cur->deliver(q, s.leaf[q].ev);
+                            s.npend = 0;
                         } else {
+                            s.awaiting = to_net;
                             s.state = Slot::WAIT_EVAL;
                             return;
                         }

@@ -79,6 +79,7 @@ class SpConfig(C.Structure):
         ("legal_net1", C.c_void_p),
         ("legal_net2", C.c_void_p),
         ("eval_threads", C.c_uint32),
+        ("leaves_in_flight", C.c_uint32),
     ]
 
 
@@ -181,6 +182,7 @@ def make_config(
     first_game: int = 0,
     game_stride: int = 1,
     eval_threads: int = 0,
+    leaves_in_flight: int = 1,
 ) -> SpConfig:
     c = SpConfig()
     c.struct_size = C.sizeof(SpConfig)
@@ -194,6 +196,7 @@ def make_config(
     c.cache_size, c.batch_size, c.threads = cache_size, batch_size, max(1, min(threads, available_cpus()))
     c.concurrent_games, c.seed, c.first_game, c.game_stride = concurrent_games, seed, first_game, game_stride
     c.eval_threads = eval_threads  # 0 = the driver's default (2 batches in flight)
+    c.leaves_in_flight = leaves_in_flight  # > 1: several leaves per tree at the network (virtual loss), not in the reference
     return c
 
 

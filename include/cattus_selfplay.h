@@ -63,6 +63,10 @@ typedef struct cattus_sp_config {
     /* threads calling the network = batches in flight (0 = 2).  libcattus_hip serves two callers
      * concurrently (one lane each), which hides transfers and launch latency behind the other batch */
     uint32_t eval_threads;
+    /* 0 or 1: the reference's sequential search.  k > 1 (at most 16; not in the reference): one tree keeps up
+     * to k unexpanded leaves at the network together, each holding a virtual loss on its path; fills
+     * batches from few concurrent games at the price of a search that differs from the sequential one */
+    uint32_t leaves_in_flight;
 } cattus_sp_config;
 
 typedef struct cattus_sp_summary {

@@ -212,3 +212,26 @@ def test_noisy_games_do_not_depend_on_schedule_or_sharding():
     # and games differ from each other (the noise is really on)
     firsts = {ref["record_bytes"][i].tobytes() for i in range(len(ref["record_bytes"])) if ref["record_meta"][i][1] == 1}
     assert len(firsts) > 1
+
+
+@pytest.mark.parametrize("game", ["hex5", "chess"])
+def test_leaves_in_flight_fills_batches_and_stays_schedule_independent(game):
+    """mcts.leaves_in_flight > 1 (virtual loss; not in the reference): one tree keeps several leaves at the
+    network, so a handful of games fills batches; the games are still a pure function of the configuration
+    (whatever the threads / batch size / evaluation threads), every record is a proper distribution over legal
+    moves, and the default (1) remains the sequential search."""
+    sims = 40 if game == "hex5" else 24
+    base = dict(sim_num=sims, cache_size=100000, concurrent_games=4)
+    seq = sp.run_self_play(game, _cfg(**base, threads=2, batch_size=32), sp.Net.stub(game), None, 4)
+    a = sp.run_self_play(game, _cfg(**base, threads=2, batch_size=32, leaves_in_flight=8), sp.Net.stub(game), None, 4)
+    b = sp.run_self_play(game, _cfg(**base, threads=4, batch_size=5, eval_threads=1, leaves_in_flight=8), sp.Net.stub(game), None, 4)
+    assert (a["record_meta"] == b["record_meta"]).all() and (a["record_bytes"] == b["record_bytes"]).all()
+    # 4 games alone give at most 4 leaves per batch; 8 leaves per tree give clearly more
+    fill_seq = seq["node_evals"] / seq["activation_count"]
+    fill_par = a["node_evals"] / a["activation_count"]
+    assert fill_seq <= 4.0 and fill_par > 1.5 * fill_seq, (fill_seq, fill_par)
+    for rec in a["record_bytes"][:40]:
+        e = records.parse_record(game, rec.tobytes())
+        legal = e.probs >= 0
+        assert legal.sum() >= 1 and abs(e.probs[legal].sum() - 1) < 1e-4
+    assert a["player1_wins"] + a["player2_wins"] + a["draws"] == 4

@@ -22,4 +22,4 @@ def test_selfplay_scheduler_is_race_free_under_tsan(tmp_path):
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-3000:]
-    assert p.stdout.count("rc=0") == 2
+    assert p.stdout.count("rc=0") == 3
