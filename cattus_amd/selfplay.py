@@ -212,6 +212,7 @@ def config_from_engine_json(cfg: dict, **overrides) -> SpConfig:
         cache_size=m["cache_size"],
         batch_size=cfg["model"]["batch_size"],
         threads=cfg["threads"],
+        leaves_in_flight=m.get("leaves_in_flight", 1),  # extension: not a key of the reference's JSON
     )
     kw.update(overrides)
     return make_config(**kw)
