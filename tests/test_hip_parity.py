@@ -275,3 +275,29 @@ def test_eval_legal_scrubbed_logits_get_zero_probability():
         probs, _ = ev.eval_legal(planes, idx, cnt)
     assert (probs[:, 3] == 0).all()
     assert abs(probs[0].sum() - 1) < 1e-5 and abs(probs[1, :5].sum() - 1) < 1e-5 and (probs[1, 5:] == 0).all()
+
+
+def test_full_size_chess_40x384_batch_512():
+    """BASELINE config 5 at full size (107 M parameters, 13.6 GFLOP per leaf, batch 512): f32 bit-exact against
+    the oracle on a few rows; every row through size-independent properties (permutation equivariance, ragged
+    sub-batch agreement); bf16 within its stated tolerance of f32 on every row."""
+    d = NetDesc(**CHESS, blocks=40, filters=384, vhc=8, phc=8)
+    blob = seeded_blob(d, 5)
+    planes = synth.random_chess_planes(512, 5)
+    perm = np.random.default_rng(1).permutation(512)
+    with HipEvaluator(blob, batch_size=512, plane_words=1, dtype="f32") as ev:
+        p32, v32 = ev.eval(planes)
+        pp, vp = ev.eval(planes[perm])
+        assert (pp == p32[perm]).all() and (vp == v32[perm]).all()
+        pr, vr = ev.eval(planes[100:357])
+        assert (pr == p32[100:357]).all() and (vr == v32[100:357]).all()
+    rows = np.array([0, 255, 511])
+    want_p, want_v = oracle.OracleNet(blob).forward(planes[rows])
+    assert (p32[rows] == want_p).all() and (v32[rows] == want_v).all()
+    with HipEvaluator(blob, batch_size=512, plane_words=1, dtype="bf16") as ev:
+        p16, v16 = ev.eval(planes)
+        pp, vp = ev.eval(planes[perm])
+        assert (pp == p16[perm]).all() and (vp == v16[perm]).all()
+    assert np.isfinite(p16).all() and np.isfinite(v16).all()
+    assert (np.abs(p16 - p32) <= BF16_POLICY_ATOL + BF16_POLICY_RTOL * np.abs(p32)).all(), np.abs(p16 - p32).max()
+    assert (np.abs(v16 - v32) <= BF16_VALUE_ATOL).all(), np.abs(v16 - v32).max()
