@@ -144,7 +144,7 @@ struct ConvLayer {
 struct ServerBatch {
     uint64_t seq = 0;
     uint32_t count = 0, collected = 0;
-    bool sealed = false, done = false;
+    bool sealed = false, running = false, done = false;
     int status = CATTUS_OK;
     std::string error;
     std::chrono::steady_clock::time_point t0;
@@ -205,7 +205,7 @@ struct cattus_eval {
     std::deque<std::unique_ptr<ServerBatch>> batches;  // oldest first; back() is collecting unless sealed
     uint64_t next_seq = 1;
     bool flush_req = false, stop = false;
-    std::thread server;
+    std::thread servers[NLANES];  // one per lane: two sealed batches can be on the device together
 
     ~cattus_eval() {
         {
@@ -214,7 +214,8 @@ struct cattus_eval {
         }
         srv_cv.notify_all();
         done_cv.notify_all();
-        if (server.joinable()) server.join();
+        for (auto& t : servers)
+            if (t.joinable()) t.join();
     }
 };
 
@@ -583,13 +584,13 @@ void server_loop(cattus_eval* e) {
         // pick the oldest batch that is sealed and not yet run; seal the collecting one on deadline/flush
         ServerBatch* run = nullptr;
         for (auto& b : e->batches)
-            if (b->sealed && !b->done) {
+            if (b->sealed && !b->done && !b->running) {
                 run = b.get();
                 break;
             }
         if (!run && !e->batches.empty()) {
             ServerBatch* cur = e->batches.back().get();
-            if (!cur->sealed && cur->count > 0) {
+            if (!cur->sealed && !cur->running && cur->count > 0) {
                 const auto deadline = cur->t0 + std::chrono::microseconds(e->cfg.flush_us);
                 if (e->flush_req || std::chrono::steady_clock::now() >= deadline) {
                     cur->sealed = true;
@@ -606,6 +607,7 @@ void server_loop(cattus_eval* e) {
             e->srv_cv.wait(lk);
             continue;
         }
+        run->running = true;
         const uint32_t n = run->count;
         run->policy.resize((size_t)n * e->d.moves);
         run->value.resize(n);
@@ -674,7 +676,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
         std::lock_guard<std::mutex> lk(e->srv_mu);
         new_batch(e.get());
     }
-    e->server = std::thread(server_loop, e.get());
+    for (auto& t : e->servers) t = std::thread(server_loop, e.get());
     *out = e.release();
     return CATTUS_OK;
 }
@@ -756,7 +758,7 @@ CATTUS_API int cattus_hip_submit(cattus_eval* e, const uint64_t* planes_one, uin
         new_batch(e);
     }
     lk.unlock();
-    if (full || slot == 0) e->srv_cv.notify_one();
+    if (full || slot == 0) e->srv_cv.notify_all();
     return CATTUS_OK;
 }
 
@@ -800,7 +802,7 @@ CATTUS_API int cattus_hip_flush(cattus_eval* e) {
         std::lock_guard<std::mutex> lk(e->srv_mu);
         e->flush_req = true;
     }
-    e->srv_cv.notify_one();
+    e->srv_cv.notify_all();
     return CATTUS_OK;
 }
 
