@@ -84,5 +84,25 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
     build_host(force, verbose)
 
 
+def build_diag(verbose: bool = False) -> None:
+    """Diagnostic builds of the same ABIs (never quote their run times):
+    libcattus_hip_diag.so with in-kernel cycle stamps (scripts/stamps.py) and libcattus_selfplay_diag.so
+    with the scheduler's worker-time split (select them with CATTUS_HIP_LIB / CATTUS_SELFPLAY_LIB)."""
+    cmds = [
+        [_hipcc(), *HIPCC_FLAGS, "-DCATTUS_STAMPS", "-o", str(PKG / "libcattus_hip_diag.so"), *map(str, HIP_SOURCES), "-lpthread"],
+        [os.environ.get("CXX") or shutil.which("g++") or "g++", *HOST_FLAGS, "-DCATTUS_SCHED_STATS", "-o",
+         str(PKG / "libcattus_selfplay_diag.so"), *map(str, HOST_SOURCES), "-lpthread"],
+    ]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+
 if __name__ == "__main__":
-    build_all(force=True, verbose=True)
+    import sys
+
+    if "--diag" in sys.argv[1:]:
+        build_diag(verbose=True)
+    else:
+        build_all(force=True, verbose=True)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic only: run the chess 20x256 batch-256 forward on the stamped build
-(cattus_amd/libcattus_hip_diag.so, -DCATTUS_STAMPS) and print where the tower kernel's cycles go.
+(cattus_amd/libcattus_hip_diag.so, -DCATTUS_STAMPS; build it with `python -m cattus_amd.build --diag`)
+and print where the tower kernel's cycles go.
 Never quote this build's run time; read the shares."""
 import ctypes as C
 import os
