@@ -34,6 +34,10 @@ WORKLOADS = {
     # configs[1] and configs[4], selectable for extra measurements
     "hex7_6x64": dict(game="hex7", blocks=6, filters=64, vhc=16, phc=16, batch=128, seed=1),
     "chess40x384": dict(game="chess", blocks=40, filters=384, vhc=8, phc=8, batch=512, seed=3),
+    # the headline net at other batch sizes (how the fixed cost per launch amortises)
+    "chess20x256_b512": dict(game="chess", blocks=20, filters=256, vhc=8, phc=8, batch=512, seed=2),
+    "chess20x256_b1024": dict(game="chess", blocks=20, filters=256, vhc=8, phc=8, batch=1024, seed=2),
+    "chess20x256_b128": dict(game="chess", blocks=20, filters=256, vhc=8, phc=8, batch=128, seed=2),
 }
 
 
