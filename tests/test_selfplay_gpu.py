@@ -97,3 +97,26 @@ def test_device_softmax_games_equal_host_restatement(game, desc, words):
     assert got["node_evals"] == want["node_evals"] > 0
     assert (got["record_meta"] == want["record_meta"]).all()
     assert (got["record_bytes"] == want["record_bytes"]).all()
+
+
+@pytest.mark.parametrize("game,size", [("tictactoe", 3), ("hex4", 4), ("hex5", 5), ("hex7", 7), ("hex9", 9), ("hex11", 11), ("chess", 8)])
+def test_full_loop_smoke_every_game(game, size):
+    """The reference's smoke loops (training/tests/test_convnetv1.py:10-58): every game with a tiny ConvNetV1,
+    sim_num 10, noise off -- here through the HIP evaluator (boards above 8x8 take the generic f32 tower) and
+    checked for well-formed records and against the same run on the CPU oracle network."""
+    info = sp.game_info(game)
+    d = NetDesc(planes=info["planes"], board=info["board"], moves=info["moves"], blocks=2, filters=16, vhc=4, phc=4)
+    blob = seeded_blob(d, 13)
+    words = info["plane_words"]
+    cfg = sp.make_config(sim_num=10, batch_size=4, threads=2, concurrent_games=4, cache_size=1000)
+    net = oracle.OracleNet(blob)
+    want = sp.run_self_play(game, cfg, sp.Net.python(lambda pl: net.forward(pl.reshape(len(pl), d.planes, words), threads=1)), None, 2)
+    with HipEvaluator(blob, batch_size=4, plane_words=words, dtype="f32") as ev:
+        got = sp.run_self_play(game, cfg, sp.Net.hip(ev), None, 2)
+    assert got["player1_wins"] + got["player2_wins"] + got["draws"] == 2
+    assert (got["record_meta"] == want["record_meta"]).all()
+    assert (got["record_bytes"] == want["record_bytes"]).all()  # f32 mode is bit-exact against the oracle
+    for rec in got["record_bytes"][:10]:
+        e = records.parse_record(game, rec.tobytes())
+        legal = e.probs >= 0
+        assert legal.sum() >= 1 and abs(e.probs[legal].sum() - 1) < 1e-4
