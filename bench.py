@@ -224,6 +224,10 @@ def main():
     # sanity: the timed kernels produced real numbers
     assert bool(torch.isfinite(d_policy).all()) and bool(torch.isfinite(d_value).all())
 
+    # roofline of the dominant kernel (3x3 conv tower launch): event-stamped launch durations of the same
+    # forward, taken right behind the timed region so that the device is in the same state as for `value`
+    launch_us, launches = ev.time_tower(batch, 20) if rank == 0 else (0.0, 1)
+
     # ---- the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
     # driver runs the evaluator: one batch's kernel tails overlap the other's heads.  Reported beside `value`.
     def time_two_lanes():
@@ -281,8 +285,6 @@ def main():
 
     if rank == 0:
         value = world * batch * args.steps / elapsed
-        # roofline of the dominant kernel (3x3 conv tower launch), timed live with HIP events
-        launch_us, launches = ev.time_tower(batch, 10)
         flop_per_launch = d.conv_flops_per_position() * batch / launches
         achieved = flop_per_launch / (launch_us * 1e-6) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]
