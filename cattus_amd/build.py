@@ -51,7 +51,7 @@ def _stale(target: Path, deps) -> bool:
 def build_hip(force: bool = False, verbose: bool = False) -> Path:
     """Compile cattus_amd/libcattus_hip.so for gfx950."""
     if force or _stale(HIP_LIB, HIP_DEPS):
-        cmd = [_hipcc(), *HIPCC_FLAGS, "-o", str(HIP_LIB), *map(str, HIP_SOURCES), "-lpthread"]
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-o", str(HIP_LIB), *map(str, HIP_SOURCES), "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -89,7 +89,7 @@ def build_diag(verbose: bool = False) -> None:
     libcattus_hip_diag.so with in-kernel cycle stamps (scripts/stamps.py) and libcattus_selfplay_diag.so
     with the scheduler's worker-time split (select them with CATTUS_HIP_LIB / CATTUS_SELFPLAY_LIB)."""
     cmds = [
-        [_hipcc(), *HIPCC_FLAGS, "-DCATTUS_STAMPS", "-o", str(PKG / "libcattus_hip_diag.so"), *map(str, HIP_SOURCES), "-lpthread"],
+        [_hipcc(), *HIPCC_FLAGS, "-DCATTUS_STAMPS", "-o", str(PKG / "libcattus_hip_diag.so"), *map(str, HIP_SOURCES), "-lpthread", "-ldl"],
         [os.environ.get("CXX") or shutil.which("g++") or "g++", *HOST_FLAGS, "-DCATTUS_SCHED_STATS", "-o",
          str(PKG / "libcattus_selfplay_diag.so"), *map(str, HOST_SOURCES), "-lpthread"],
     ]

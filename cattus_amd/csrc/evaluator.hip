@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/cattus_hip.h"
 #include "kernels.h"
 
@@ -129,6 +131,42 @@ struct PinnedBuf {
 // page-locked host ranges handed out by cattus_hip_host_alloc
 std::mutex g_pin_mu;
 std::vector<std::pair<const char*, size_t>> g_pinned;
+// Optional ROCTx ranges around every batch (CATTUS_ROCTX=1): they show up in `rocprofv3 --marker-trace`.
+// The library is looked up at run time so that nothing links against the profiler.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* on = getenv("CATTUS_ROCTX");
+        if (!on || on[0] != '1') return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr, pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+struct RoctxRange {
+    bool on;
+    RoctxRange(const char* what, uint32_t n) : on(roctx().push != nullptr) {
+        if (on) {
+            char buf[64];
+            snprintf(buf, sizeof buf, "%s n=%u", what, n);
+            roctx().push(buf);
+        }
+    }
+    ~RoctxRange() {
+        if (on) roctx().pop();
+    }
+};
+
 bool is_pinned(const void* p) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (auto& r : g_pinned)
@@ -512,6 +550,7 @@ int eval_host(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy,
         lk = std::unique_lock<std::mutex>(lane->mu);
     }
     Lane& L = *lane;
+    const RoctxRange range(lg ? "cattus_hip_eval_legal" : "cattus_hip_eval", n);
     HIP_TRY(hipSetDevice(e->device));
     const auto t0 = std::chrono::steady_clock::now();
     const size_t pbytes = (size_t)n * d.planes * e->cfg.plane_words * 8;
