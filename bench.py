@@ -142,7 +142,7 @@ def selfplay_leg(ev_blob, d, dtype: str, local_rank: int, rank: int, world: int,
     with HipEvaluator(ev_blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
         cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
                              temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25,
-                             first_game=rank, game_stride=world, seed=1 + rank)
+                             first_game=rank, game_stride=world, seed=1)  # random streams are per global game index
         t0 = time.perf_counter()
         res = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, games, keep_records=False)
         dt = time.perf_counter() - t0

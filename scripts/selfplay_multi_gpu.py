@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--concurrent-games", type=int, default=64)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--diverse", action="store_true", help="temperature 1.0 for 30 moves + Dirichlet noise (chess_dev.yaml)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--leaves-in-flight", type=int, default=1, help="> 1: virtual-loss leaf parallelism per tree (not the reference's search)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
@@ -61,7 +63,8 @@ def main():
     first, stride, local_games = cdist.shard_games(args.games_num, rank, world)
     kw = dict(temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25) if args.diverse else {}
     cfg = sp.make_config(sim_num=args.sim_num, batch_size=args.batch_size, threads=args.threads, concurrent_games=args.concurrent_games,
-                         cache_size=1000000, first_game=first, game_stride=stride, seed=1 + rank, **kw)
+                         cache_size=1000000, first_game=first, game_stride=stride, seed=args.seed,
+                         leaves_in_flight=args.leaves_in_flight, **kw)  # random streams are per global game index: same seed on every rank
     ev = None
     if args.net == "hip":
         from cattus_amd.evaluator import HipEvaluator
