@@ -30,6 +30,20 @@ def test_oracle_matches_reference_net(name):
 
 
 @pytest.mark.parametrize("name", golden_names())
+def test_oracle_intermediate_activations_match_reference_module(name):
+    """Layer-level pin: the stem ConvBlock output and the output of the last residual block of the
+    reference module (forward hooks in oracle/gen_golden.py) against the oracle's own intermediates, so that a
+    BatchNorm-folding or skip-connection error cannot hide behind the heads."""
+    d, blob, z = blob_for(name)
+    _, _, stem, tower = oracle.OracleNet(blob).forward_debug(z["planes"][0])
+    np.testing.assert_allclose(stem, z["stem0"], rtol=1e-4, atol=1e-5)
+    if name in DEEP:
+        np.testing.assert_allclose(tower, z["tower0"], rtol=2e-3, atol=2e-4)
+    else:
+        np.testing.assert_allclose(tower, z["tower0"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", golden_names())
 def test_oracle_planes_to_tensor(name):
     d, blob, z = blob_for(name)
     planes = z["planes"]
