@@ -301,3 +301,30 @@ def test_full_size_chess_40x384_batch_512():
     assert np.isfinite(p16).all() and np.isfinite(v16).all()
     assert (np.abs(p16 - p32) <= BF16_POLICY_ATOL + BF16_POLICY_RTOL * np.abs(p32)).all(), np.abs(p16 - p32).max()
     assert (np.abs(v16 - v32) <= BF16_VALUE_ATOL).all(), np.abs(v16 - v32).max()
+
+
+def test_device_pointer_entry_points_and_lanes_agree_with_host_entry_point():
+    """cattus_hip_eval_device / _lane (HBM-resident buffers, asynchronous on a caller's stream; what bench.py
+    times) give bit for bit what the blocking host-buffer entry point gives, on either lane and with both
+    lanes in flight on two streams."""
+    torch = pytest.importorskip("torch")
+    d = NetDesc(**CHESS, blocks=3, filters=64, vhc=8, phc=8)
+    blob = seeded_blob(d, 8)
+    planes = synth.random_chess_planes(96, 8)
+    dev = torch.device("cuda", 0)
+    with HipEvaluator(blob, batch_size=128, plane_words=1, dtype="bf16") as ev:
+        want_p, want_v = ev.eval(planes)
+        d_planes = torch.from_numpy(planes.view(np.int64)).to(dev)
+        outs = []
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        for rep in range(3):
+            for lane in (0, 1):
+                pol = torch.empty((96, d.moves), dtype=torch.float32, device=dev)
+                val = torch.empty((96,), dtype=torch.float32, device=dev)
+                ev.eval_device(d_planes.data_ptr(), 96, pol.data_ptr(), val.data_ptr(), streams[lane].cuda_stream, lane=lane)
+                outs.append((pol, val))
+        torch.cuda.synchronize()
+        for pol, val in outs:
+            assert (pol.cpu().numpy() == want_p).all() and (val.cpu().numpy() == want_v).all()
+        with pytest.raises(CattusHipError):
+            ev.eval_device(d_planes.data_ptr(), 96, outs[0][0].data_ptr(), outs[0][1].data_ptr(), 0, lane=2)
