@@ -14,9 +14,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -128,9 +130,10 @@ struct PinnedBuf {
     }
 };
 
-// page-locked host ranges handed out by cattus_hip_host_alloc
-std::mutex g_pin_mu;
-std::vector<std::pair<const char*, size_t>> g_pinned;
+// page-locked host ranges handed out by cattus_hip_host_alloc: start -> length.  Every evaluation probes
+// this (three pointers per batch, from several threads), allocation is rare: readers share the lock.
+std::shared_mutex g_pin_mu;
+std::map<const char*, size_t> g_pinned;
 // Optional ROCTx ranges around every batch (CATTUS_ROCTX=1): they show up in `rocprofv3 --marker-trace`.
 // The library is looked up at run time so that nothing links against the profiler.
 struct Roctx {
@@ -168,10 +171,11 @@ struct RoctxRange {
 };
 
 bool is_pinned(const void* p) {
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    for (auto& r : g_pinned)
-        if ((const char*)p >= r.first && (const char*)p < r.first + r.second) return true;
-    return false;
+    std::shared_lock<std::shared_mutex> lk(g_pin_mu);
+    auto it = g_pinned.upper_bound((const char*)p);
+    if (it == g_pinned.begin()) return false;
+    --it;
+    return (const char*)p < it->first + it->second;
 }
 
 struct ConvLayer {
@@ -188,6 +192,7 @@ struct ServerBatch {
     std::chrono::steady_clock::time_point t0;
     std::vector<uint64_t> planes;
     std::vector<float> policy, value;
+    std::vector<uint8_t> taken;  // per slot: its ticket has been waited for
 };
 
 constexpr int NLANES = CATTUS_HIP_LANES;
@@ -198,8 +203,6 @@ struct Lane {
     DevBuf d_legal_idx, d_legal_cnt, d_probs;  // legal-move softmax operands, allocated on first use
     uint32_t legal_stride = 0;
     PinnedBuf h_planes, h_policy, h_value;
-    DevBuf tower_counters, tower_err;  // persistent tower: hand-off counters, time-out flag
-    PinnedBuf h_tower_err;
     std::mutex mu;  // held while a batch uses the lane
     ~Lane() {
         if (stream) (void)hipStreamDestroy(stream);
@@ -229,11 +232,6 @@ struct cattus_eval {
     Lane lanes[NLANES];
     std::atomic<unsigned> lane_rr{0};
 
-    // persistent tower (one launch for all 3x3 layers): layer table (shared), per-lane counters/flags
-    std::atomic<bool> persistent{false};
-    DevBuf tower_layers;
-    uint32_t tower_out_buf = 1;  // index (1..3) of the buffer holding the tower output
-    bool tower_xcd_local = false;  // hand-off through one XCD's L2 (CATTUS_TOWER=persistent-xcd)
     std::mutex stat_mu;
     cattus_stats stats{};
 
@@ -378,27 +376,6 @@ int build(cattus_eval* e, const float* p) {
     const size_t bp_ = e->bpad, B = e->cfg.max_batch;
     const size_t esz = e->tuned ? (size_t)act_bytes(e->act) : 4;
     const size_t slots = e->tuned ? SLOTS : hw;
-    size_t nlayers = 0;
-    if (e->tuned) {
-        std::vector<TowerLayer> tl;
-        int cur = 1;  // buffers: 0 = x0, 1 = a, 2 = t, 3 = y
-        tl.push_back(TowerLayer{e->stem.w.p, e->stem.b.as<float>(), 0, -1, cur, (int)e->cpad0});
-        for (uint32_t i = 0; i < d.blocks; i++) {
-            const int nxt = cur == 1 ? 3 : 1;
-            tl.push_back(TowerLayer{e->c1[i]->w.p, e->c1[i]->b.as<float>(), cur, -1, 2, (int)F});
-            tl.push_back(TowerLayer{e->c2[i]->w.p, e->c2[i]->b.as<float>(), 2, cur, nxt, (int)F});
-            cur = nxt;
-        }
-        e->tower_out_buf = (uint32_t)cur;
-        nlayers = tl.size();
-        if ((rc = e->tower_layers.upload(tl.data(), tl.size() * sizeof(TowerLayer)))) return rc;
-        // Default: one launch per layer.  CATTUS_TOWER=persistent selects the single-launch tower with
-        // in-kernel hand-offs between the workgroups of a board group (measured +2 % on chess 20x256 at
-        // batch 256; it needs those workgroups resident together and falls back on a time-out).
-        const char* mode = getenv("CATTUS_TOWER");
-        e->persistent = mode && (strcmp(mode, "persistent") == 0 || strcmp(mode, "persistent-xcd") == 0);
-        e->tower_xcd_local = mode && strcmp(mode, "persistent-xcd") == 0;
-    }
     for (Lane& L : e->lanes) {
         HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         if ((rc = L.d_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
@@ -411,14 +388,6 @@ int build(cattus_eval* e, const float* p) {
         if ((rc = L.h1.alloc(bp_ * FC_HIDDEN * 4))) return rc;
         if ((rc = L.d_policy.alloc(B * d.moves * 4))) return rc;
         if ((rc = L.d_value.alloc(B * 4))) return rc;
-        if (e->tuned) {
-            const size_t ncnt = (size_t)(bp_ / BOARDS_PER_WG) * nlayers * 8;
-            if ((rc = L.tower_counters.alloc(ncnt * 4))) return rc;
-            if ((rc = L.tower_err.alloc(16))) return rc;
-            HIP_TRY(hipMemset(L.tower_err.p, 0, 16));
-            if ((rc = L.h_tower_err.alloc(16))) return rc;
-            *L.h_tower_err.as<unsigned>() = 0;
-        }
         if ((rc = L.h_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
         if ((rc = L.h_policy.alloc(B * d.moves * 4))) return rc;
         if ((rc = L.h_value.alloc(B * 4))) return rc;
@@ -448,23 +417,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
     if (e->tuned) {
         nb = (n + BOARDS_PER_WG - 1) / BOARDS_PER_WG * BOARDS_PER_WG;
         launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
-        if (e->persistent) {
-            // one launch for the whole tower; hand-off counters are re-zeroed by a memset node in front of it
-            const uint32_t nlayers = 1 + 2 * d.blocks;
-            const size_t ncnt = (size_t)(nb / BOARDS_PER_WG) * nlayers * 8;
-            (void)hipMemsetAsync(L.tower_counters.p, 0, ncnt * 4, st);
-            TowerArgs ta{};
-            ta.buf[0] = L.x0.p, ta.buf[1] = L.a.p, ta.buf[2] = L.t.p, ta.buf[3] = L.y.p;
-            ta.layers = e->tower_layers.as<TowerLayer>();
-            ta.counters = L.tower_counters.as<unsigned>();
-            ta.err = L.tower_err.as<unsigned>();
-            ta.nlayers = (int)nlayers, ta.cout = (int)F, ta.S = (int)S;
-            ta.spin_budget_ticks = 2000000;  // 20 ms
-            ta.xcd_local = e->tower_xcd_local ? 1 : 0;
-            hipEvent_t s0 = ev(false), s1 = ev(true);
-            launch_tower_persistent(e->act, ta, nb, st, s0, s1);
-            a = ta.buf[e->tower_out_buf];
-        } else {
+        {
             hipEvent_t s0 = ev(false), s1 = ev(true);
             launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, F, S, st, s0, s1);
             for (uint32_t i = 0; i < d.blocks; i++) {
@@ -588,19 +541,7 @@ int eval_host(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy,
         return CATTUS_OK;
     };
     if ((rc = copy_out())) return rc;
-    if (e->persistent)
-        HIP_TRY(hipMemcpyAsync(L.h_tower_err.p, L.tower_err.p, 4, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
-    if (e->persistent && *L.h_tower_err.as<unsigned>() != 0) {
-        // a hand-off wait timed out (workgroups of one board group were not resident together): the result
-        // of this pass is not trustworthy.  Fall back to one launch per layer, for good.
-        e->persistent = false;
-        fprintf(stderr, "cattus_hip: persistent tower timed out; using per-layer launches from now on\n");
-        rc = enqueue_forward(e, L, L.d_planes.as<uint64_t>(), n, L.d_policy.as<float>(), L.d_value.as<float>(), L.stream);
-        if (rc) return rc;
-        if ((rc = copy_out())) return rc;
-        HIP_TRY(hipStreamSynchronize(L.stream));
-    }
     if (!direct) {
         if (!lg) memcpy(policy, L.h_policy.p, (size_t)n * d.moves * 4);
         memcpy(value, L.h_value.p, (size_t)n * 4);
@@ -650,6 +591,7 @@ void server_loop(cattus_eval* e) {
         const uint32_t n = run->count;
         run->policy.resize((size_t)n * e->d.moves);
         run->value.resize(n);
+        run->taken.assign(n, 0);
         lk.unlock();
         const int rc = eval_host(e, run->planes.data(), n, run->policy.data(), run->value.data());
         std::string err = rc ? g_last_error : std::string();
@@ -763,19 +705,20 @@ CATTUS_API int cattus_hip_eval_device_lane(cattus_eval* e, uint32_t lane, const 
     Lane& L = e->lanes[lane];
     std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
-    hipStream_t st = stream ? (hipStream_t)stream : L.stream;
-    if (e->persistent && *L.h_tower_err.as<unsigned>() != 0) {
-        // reported by an earlier asynchronous pass (copied back below): stop using the persistent tower
-        e->persistent = false;
-        fprintf(stderr, "cattus_hip: persistent tower timed out; using per-layer launches from now on\n");
-    }
+    hipStream_t st = (hipStream_t)stream;  // as HIP itself: NULL is the legacy default stream, not a private one
     int rc = enqueue_forward(e, L, d_planes, n, d_policy, d_value, st);
     if (rc) return rc;
-    if (e->persistent) HIP_TRY(hipMemcpyAsync(L.h_tower_err.p, L.tower_err.p, 4, hipMemcpyDeviceToHost, st));
     std::lock_guard<std::mutex> sl(e->stat_mu);
     e->stats.batches += 1;
     e->stats.positions += n;
     if (n == e->cfg.max_batch) e->stats.full_batches += 1;
+    return CATTUS_OK;
+}
+
+CATTUS_API int cattus_hip_lane_stream(cattus_eval* e, uint32_t lane, void** stream) {
+    if (!e || !stream) return fail(CATTUS_E_INVALID, "NULL argument");
+    if (lane >= NLANES) return fail(CATTUS_E_INVALID, "lane %u out of range (%d lanes)", lane, NLANES);
+    *stream = (void*)e->lanes[lane].stream;
     return CATTUS_OK;
 }
 
@@ -815,12 +758,16 @@ CATTUS_API int cattus_hip_wait(cattus_eval* e, uint64_t ticket, float* policy, f
             }
         if (!b || slot >= b->count) return fail(CATTUS_E_STATE, "unknown or already collected ticket %llu", (unsigned long long)ticket);
         if (b->done) {
-            if (b->status != CATTUS_OK) {
+            // a ticket is single-use whether its batch succeeded or not: the last waiter through erases the batch
+            if (slot >= b->taken.size() || b->taken[slot]) return fail(CATTUS_E_STATE, "ticket %llu was already collected", (unsigned long long)ticket);
+            b->taken[slot] = 1;
+            const int status = b->status;
+            if (status != CATTUS_OK) {
                 g_last_error = b->error;
-                return b->status;
+            } else {
+                memcpy(policy, b->policy.data() + (size_t)slot * e->d.moves, (size_t)e->d.moves * 4);
+                *value = b->value[slot];
             }
-            memcpy(policy, b->policy.data() + (size_t)slot * e->d.moves, (size_t)e->d.moves * 4);
-            *value = b->value[slot];
             if (++b->collected == b->count) {
                 for (auto it = e->batches.begin(); it != e->batches.end(); ++it)
                     if (it->get() == b) {
@@ -828,7 +775,7 @@ CATTUS_API int cattus_hip_wait(cattus_eval* e, uint64_t ticket, float* policy, f
                         break;
                     }
             }
-            return CATTUS_OK;
+            return status;
         }
         if (e->stop) return fail(CATTUS_E_STATE, "evaluator is shutting down");
         e->done_cv.wait(lk);
@@ -851,20 +798,16 @@ CATTUS_API void* cattus_hip_host_alloc(size_t bytes) {
         fail(CATTUS_E_NOMEM, "hipHostMalloc(%zu) failed", bytes);
         return nullptr;
     }
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    g_pinned.emplace_back((const char*)p, bytes);
+    std::unique_lock<std::shared_mutex> lk(g_pin_mu);
+    g_pinned[(const char*)p] = bytes ? bytes : 16;
     return p;
 }
 
 CATTUS_API void cattus_hip_host_free(void* p) {
     if (!p) return;
     {
-        std::lock_guard<std::mutex> lk(g_pin_mu);
-        for (auto it = g_pinned.begin(); it != g_pinned.end(); ++it)
-            if (it->first == (const char*)p) {
-                g_pinned.erase(it);
-                break;
-            }
+        std::unique_lock<std::shared_mutex> lk(g_pin_mu);
+        g_pinned.erase((const char*)p);
     }
     (void)hipHostFree(p);
 }
@@ -882,7 +825,7 @@ CATTUS_API int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, 
     Lane& L = e->lanes[0];
     std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
-    const uint32_t per_fwd = (e->tuned && e->persistent) ? 1 : 1 + 2 * e->d.blocks;
+    const uint32_t per_fwd = 1 + 2 * e->d.blocks;
     TowerTimer tt;
     tt.ev.resize((size_t)2 * per_fwd);
     for (auto& ev : tt.ev) HIP_TRY(hipEventCreate(&ev));

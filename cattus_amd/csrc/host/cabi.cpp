@@ -36,7 +36,7 @@ SelfPlayConfig to_config(const cattus_sp_config* c) {
     cfg.mcts.explore_factor = c->explore_factor;
     // temperature_policy: all entries but the last are (threshold, T); the last entry's T is the tail
     // (self_play_cmd.rs:73-76)
-    const uint32_t n = std::min<uint32_t>(c->temperature_count, 8);
+    const uint32_t n = c->temperature_count;  // 1..8, checked by config_error()
     for (uint32_t i = 0; i + 1 < n; i++) cfg.mcts.temperature.scheduled.emplace_back(c->temperature_threshold[i], c->temperature_value[i]);
     cfg.mcts.temperature.last = n ? c->temperature_value[n - 1] : 0.0f;
     cfg.mcts.prior_noise_alpha = c->prior_noise_alpha;
@@ -53,6 +53,21 @@ SelfPlayConfig to_config(const cattus_sp_config* c) {
     cfg.eval_threads = c->eval_threads ? std::min(c->eval_threads, 8u) : 2;
     cfg.mcts.leaves_in_flight = std::max(1u, std::min(c->leaves_in_flight, 16u));
     return cfg;
+}
+
+// What TemperaturePolicy::scheduled asserts (mcts/mod.rs:463-476) plus the limits of the C struct; nullptr = ok.
+const char* config_error(const cattus_sp_config* c) {
+    if (!c || c->struct_size != sizeof(cattus_sp_config)) return "bad config struct";
+    if (c->sim_num < 2) return "sim_num must be > 1";
+    if (c->temperature_count < 1 || c->temperature_count > 8) return "temperature_count must be 1..8";
+    for (uint32_t i = 0; i < c->temperature_count; i++) {
+        if (!(c->temperature_value[i] >= 0.0f)) return "temperatures must be >= 0";
+        if (i > 0 && i + 1 < c->temperature_count && c->temperature_threshold[i] <= c->temperature_threshold[i - 1])
+            return "temperature thresholds must be strictly increasing";
+    }
+    if (!(c->explore_factor >= 0.0f) || !(c->prior_noise_alpha >= 0.0f)) return "explore_factor / prior_noise_alpha must be >= 0";
+    if (!(c->prior_noise_epsilon >= 0.0f && c->prior_noise_epsilon <= 1.0f)) return "prior_noise_epsilon must be in [0, 1]";
+    return nullptr;
 }
 
 // ---- position handles ----
@@ -212,12 +227,12 @@ SP_API int cattus_sp_game_info(int game, uint32_t out[5]) {
 SP_API int cattus_sp_run(int game, const cattus_sp_config* c, cattus_net_eval_fn net1, void* ctx1, cattus_net_eval_fn net2,
                          void* ctx2, uint32_t games_num, const char* out_dir1, const char* out_dir2, int keep_records,
                          cattus_sp_result** out) {
-    if (!c || c->struct_size != sizeof(cattus_sp_config) || !net1 || !out) {
+    if (!net1 || !out) {
         g_err = "bad arguments";
         return -1;
     }
-    if (c->sim_num < 2) {
-        g_err = "sim_num must be > 1";
+    if (const char* why = config_error(c)) {
+        g_err = why;
         return -1;
     }
     *out = nullptr;
@@ -288,9 +303,16 @@ SP_API int cattus_sp_stub_net(void* ctx, const uint64_t* planes, uint32_t n, flo
     return 0;
 }
 
-SP_API int64_t cattus_sp_trace_game(int game, const cattus_sp_config* c, cattus_net_eval_fn net, void* ctx, uint32_t max_plies,
-                                    uint32_t* out, size_t cap) {
-    if (!c || c->struct_size != sizeof(cattus_sp_config) || !net || !out || c->sim_num < 2) return -1;
+SP_API int64_t cattus_sp_trace_game_ex(int game, const cattus_sp_config* c, cattus_net_eval_fn net, void* ctx, uint32_t max_plies,
+                                       const uint16_t* forced, uint32_t n_forced, uint32_t search_from, uint32_t* out, size_t cap) {
+    if (!net || !out || (n_forced && !forced)) {
+        g_err = "bad arguments";
+        return -1;
+    }
+    if (const char* why = config_error(c)) {
+        g_err = why;
+        return -1;
+    }
     int64_t written = -1;
     dispatch(game, [&](auto g) -> int {
         typedef decltype(g) G;
@@ -300,48 +322,105 @@ SP_API int64_t cattus_sp_trace_game(int game, const cattus_sp_config* c, cattus_
         NetValueFunction<G> vf(NetHandle{net, ctx}, cfg.cache_size, &metrics);
         // exactly what one reference worker does for game 0: two persistent players (self_play.rs:180-217)
         MctsPlayer<G> p1(cfg.mcts, cfg.seed * 2 + 1), p2(cfg.mcts, cfg.seed * 2 + 2);
-        std::vector<typename G::Position> history{G::Position::initial()};
-        bool repetition = false;
+        GameState<G> gs;
+        gs.reset(G::Position::initial());
         size_t w = 1;
-        uint32_t plies = 0;
+        uint32_t plies = 0, searched = 0;
         std::vector<float> policy(G::MOVES);
-        while (plies < max_plies) {
-            if (repetition || history.back().status().finished) break;
-            MctsPlayer<G>& cur = history.back().turn() == PLAYER1 ? p1 : p2;
-            cur.begin_search(history);
-            while (cur.advance(history) == MctsPlayer<G>::NEED_EVAL) {
-                PendingLeaf<G> pend;
-                Evaluation<G> ev;
-                if (!vf.prepare(cur.pending_position(), pend, ev)) {
-                    float value = 0;
-                    if (net(ctx, pend.planes, 1, policy.data(), &value) != 0) return 0;
-                    vf.finish(pend, policy.data(), value, ev);
+        std::vector<typename G::Move> legal;
+        while (searched < max_plies) {
+            if (gs.status().finished) break;
+            typename G::Move m{};
+            bool have_move = false;
+            if (plies < n_forced) {
+                gs.history.back().legal_moves(legal);
+                for (auto& lm : legal)
+                    if ((uint16_t)lm.nn_idx() == forced[plies]) m = lm, have_move = true;
+                if (!have_move) {
+                    g_err = "forced move " + std::to_string(forced[plies]) + " is not legal at ply " + std::to_string(plies);
+                    return 0;
                 }
-                cur.deliver(ev);
             }
-            const auto visits = cur.root_visits();
-            const auto probs = cur.result();
-            typename G::Move m;
-            if (!cur.choose_move(history, probs, m)) return 0;
-            if (w + 2 + 2 * visits.size() > cap) return 0;
-            out[w++] = (uint32_t)m.nn_idx();
-            out[w++] = (uint32_t)visits.size();
-            for (auto& v : visits) out[w++] = (uint32_t)v.first.nn_idx(), out[w++] = v.second;
-            typename G::Position np = history.back().moved(m);
-            if (G::REPETITION_LIMIT > 1) {
-                int cnt = 1;
-                for (auto& p : history)
-                    if (p == np) cnt++;
-                if (cnt >= G::REPETITION_LIMIT) repetition = true;
+            if (plies >= search_from) {
+                MctsPlayer<G>& cur = gs.history.back().turn() == PLAYER1 ? p1 : p2;
+                cur.begin_search(gs.history);
+                while (cur.advance(gs.history) == MctsPlayer<G>::NEED_EVAL) {
+                    PendingLeaf<G> pend;
+                    Evaluation<G> ev;
+                    if (!vf.prepare(cur.pending_position(), pend, ev)) {
+                        float value = 0;
+                        if (net(ctx, pend.planes, 1, policy.data(), &value) != 0) {
+                            g_err = "network callback failed";
+                            return 0;
+                        }
+                        vf.finish(pend, policy.data(), value, ev);
+                    }
+                    cur.deliver(ev);
+                }
+                const auto visits = cur.root_visits();
+                const auto probs = cur.result();
+                typename G::Move chosen;
+                if (!cur.choose_move(gs.history, probs, chosen)) {
+                    g_err = "search returned no move";
+                    return 0;
+                }
+                if (w + 2 + 2 * visits.size() > cap) {
+                    g_err = "trace buffer too small";
+                    return 0;
+                }
+                out[w++] = (uint32_t)chosen.nn_idx();
+                out[w++] = (uint32_t)visits.size();
+                for (auto& v : visits) out[w++] = (uint32_t)v.first.nn_idx(), out[w++] = v.second;
+                searched++;
+                if (!have_move) m = chosen;
+            } else if (!have_move) {
+                g_err = "no forced move for ply " + std::to_string(plies) + " before search_from";
+                return 0;
             }
-            history.push_back(np);
+            gs.play(m);
             plies++;
         }
-        out[0] = plies;
+        out[0] = searched;
         written = (int64_t)w;
         return 1;
     });
     return written;
+}
+
+SP_API int64_t cattus_sp_trace_game(int game, const cattus_sp_config* c, cattus_net_eval_fn net, void* ctx, uint32_t max_plies,
+                                    uint32_t* out, size_t cap) {
+    return cattus_sp_trace_game_ex(game, c, net, ctx, max_plies, nullptr, 0, 0, out, cap);
+}
+
+SP_API int cattus_sp_play_moves(int game, const uint16_t* moves, uint32_t n, uint32_t* plies_played) {
+    int status = -100;
+    dispatch(game, [&](auto g) -> int {
+        typedef decltype(g) G;
+        GameState<G> gs;
+        gs.reset(G::Position::initial());
+        std::vector<typename G::Move> legal;
+        uint32_t k = 0;
+        for (; k < n; k++) {
+            if (gs.status().finished) break;  // play_single_turn asserts the game is ongoing (chess/core.rs:439)
+            gs.history.back().legal_moves(legal);
+            bool ok = false;
+            for (auto& lm : legal)
+                if ((uint16_t)lm.nn_idx() == moves[k]) {
+                    gs.play(lm), ok = true;
+                    break;
+                }
+            if (!ok) {
+                g_err = "move " + std::to_string(moves[k]) + " is not legal at ply " + std::to_string(k);
+                status = -101;
+                return 0;
+            }
+        }
+        if (plies_played) *plies_played = k;
+        const Status st = gs.status();
+        status = st.finished ? st.winner : 2;
+        return 1;
+    });
+    return status;
 }
 
 SP_API cattus_pos* cattus_sp_pos_new(int game, const char* str) {

@@ -162,11 +162,12 @@ class MctsPlayer {
     const Position& pending_position(uint32_t i = 0) const { return nodes_[inflight_[i].leaf].pos; }
 
     // second half of a simulation: create_children, root noise, backpropagate (mcts/mod.rs:179-194)
-    void deliver(const Evaluation<G>& ev) { deliver(0, ev); }
-    void deliver(uint32_t i, const Evaluation<G>& ev) {
-        assert(i < inflight_n_);
+    // Returns false (and changes nothing) for an index that is not waiting: out of range or delivered before.
+    bool deliver(const Evaluation<G>& ev) { return deliver(0, ev); }
+    bool deliver(uint32_t i, const Evaluation<G>& ev) {
+        if (i >= inflight_n_) return false;
         const InFlight& f = inflight_[i];
-        if (nodes_[f.leaf].pending == 0) return;  // already delivered
+        if (nodes_[f.leaf].pending == 0) return false;  // delivered before: every leaf counts once
         nodes_[f.leaf].pending = 0;
         for (uint32_t e : f.path)
             if (edges_[e].vl) edges_[e].vl--;
@@ -175,6 +176,7 @@ class MctsPlayer {
         backpropagate(f.path, ev.value);
         sims_done_++;
         if (++delivered_ == inflight_n_) inflight_n_ = 0;
+        return true;
     }
 
     // calc_moves_probabilities, second half (mcts/mod.rs:363-379): (move, n / sum n) in edges() order

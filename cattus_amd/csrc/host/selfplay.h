@@ -61,16 +61,19 @@ struct Metrics {
 };
 
 // ---- evaluation cache (mcts/cache.rs): key = position flipped to Player1, FIFO eviction -----------
+// One FIFO of max_size positions, as the reference's single deque (cache.rs:62-66), so that evictions --
+// and with them the cache.hits / cache.misses counters of the summary -- are those of a reference run with
+// the same evaluation order.  The reference guards map and deque with one RwLock; here the map is split
+// into shards (a probe locks 1/64 of it) and only the eviction order is global.
 template <typename G>
 class EvalCache {
    public:
-    explicit EvalCache(size_t max_size) : max_size_(max_size ? max_size : 1) {
-        per_shard_ = (max_size_ + SHARDS - 1) / SHARDS;
-    }
+    explicit EvalCache(size_t max_size) : max_size_(max_size ? max_size : 1) {}
     bool get(const typename G::Position& pos, Evaluation<G>& out) {
-        Shard& s = shards_[pos.hash() % SHARDS];
+        const uint64_t h = pos.hash();
+        Shard& s = shards_[h % SHARDS];
         std::lock_guard<std::mutex> lk(s.mu);
-        auto range = s.map.equal_range(pos.hash());
+        auto range = s.map.equal_range(h);
         for (auto it = range.first; it != range.second; ++it)
             if (it->second.first == pos) {
                 out = it->second.second;
@@ -80,27 +83,47 @@ class EvalCache {
     }
     // returns false if the position was already present (the reference then returns the cached value)
     bool insert(const typename G::Position& pos, const Evaluation<G>& ev, Evaluation<G>* existing) {
-        Shard& s = shards_[pos.hash() % SHARDS];
-        std::lock_guard<std::mutex> lk(s.mu);
-        auto range = s.map.equal_range(pos.hash());
-        for (auto it = range.first; it != range.second; ++it)
-            if (it->second.first == pos) {
-                if (existing) *existing = it->second.second;
-                return false;
-            }
-        while (s.fifo.size() >= per_shard_) {
-            const auto& old = s.fifo.front();
-            auto r = s.map.equal_range(old.hash());
-            for (auto it = r.first; it != r.second; ++it)
-                if (it->second.first == old) {
-                    s.map.erase(it);
-                    break;
+        const uint64_t h = pos.hash();
+        // The FIFO lock is held across the whole insert, like the reference's write lock: "evict while
+        // len >= max_size, then push" (cache.rs:62-70) stays atomic.  Shard locks nest inside it, never
+        // the other way round.
+        std::lock_guard<std::mutex> fl(fifo_mu_);
+        {
+            Shard& s = shards_[h % SHARDS];
+            std::lock_guard<std::mutex> lk(s.mu);
+            auto range = s.map.equal_range(h);
+            for (auto it = range.first; it != range.second; ++it)
+                if (it->second.first == pos) {
+                    if (existing) *existing = it->second.second;
+                    return false;
                 }
-            s.fifo.pop_front();
         }
-        s.map.emplace(pos.hash(), std::make_pair(pos, ev));
-        s.fifo.push_back(pos);
+        while (fifo_.size() >= max_size_) {
+            const typename G::Position& old = fifo_.front();
+            const uint64_t oh = old.hash();
+            Shard& os = shards_[oh % SHARDS];
+            {
+                std::lock_guard<std::mutex> lk(os.mu);
+                auto r = os.map.equal_range(oh);
+                for (auto it = r.first; it != r.second; ++it)
+                    if (it->second.first == old) {
+                        os.map.erase(it);
+                        break;
+                    }
+            }
+            fifo_.pop_front();
+        }
+        {
+            Shard& s = shards_[h % SHARDS];
+            std::lock_guard<std::mutex> lk(s.mu);
+            s.map.emplace(h, std::make_pair(pos, ev));
+        }
+        fifo_.push_back(pos);
         return true;
+    }
+    size_t size() {
+        std::lock_guard<std::mutex> fl(fifo_mu_);
+        return fifo_.size();
     }
 
    private:
@@ -108,10 +131,11 @@ class EvalCache {
     struct Shard {
         std::mutex mu;
         std::unordered_multimap<uint64_t, std::pair<typename G::Position, Evaluation<G>>> map;
-        std::deque<typename G::Position> fifo;
     };
     Shard shards_[SHARDS];
-    size_t max_size_, per_shard_;
+    std::mutex fifo_mu_;
+    std::deque<typename G::Position> fifo_;
+    size_t max_size_;
 };
 
 // ---- NNetwork::evaluate split around the network call ---------------------------------------------
@@ -239,6 +263,32 @@ struct Serializer {
     }
 };
 
+// Game::{new, status, play_single_turn} (game/mod.rs:70-107; chess/core.rs:405-451): the position history
+// plus, for games with a repetition limit, the "a position occurred REPETITION_LIMIT times" draw flag.
+template <typename G>
+struct GameState {
+    std::vector<typename G::Position> history;
+    bool repetition_detected = false;
+    void reset(const typename G::Position& start) {
+        history.assign(1, start);
+        repetition_detected = false;
+    }
+    Status status() const {  // ChessGame::status (chess/core.rs:431-436) / the position's own status
+        if (repetition_detected) return Status::draw();
+        return history.back().status();
+    }
+    void play(const typename G::Move& m) {  // play_single_turn (chess/core.rs:438-450)
+        typename G::Position np = history.back().moved(m);
+        if (G::REPETITION_LIMIT > 1) {
+            int cnt = 1;  // seen_positions counts the new position itself
+            for (auto& p : history)
+                if (p == np) cnt++;
+            if (cnt >= G::REPETITION_LIMIT) repetition_detected = true;
+        }
+        history.push_back(np);
+    }
+};
+
 struct Record {
     uint32_t game_idx, pos_idx;
     uint8_t dir;  // 0 -> out_dir1, 1 -> out_dir2
@@ -321,14 +371,22 @@ class SelfPlayRunner {
         int rc = 0;
         for (uint32_t i = 0; i < nslots; i++) ready.push_back(i);
 
-        // ring of batch buffers: a buffer is reusable once every leaf of its batch has been consumed
-        constexpr int NBUF = 6;
+        // Ring of batch buffers: a buffer is reusable once every leaf of its batch has been consumed.  A slot
+        // consumes its rows only when ALL its leaves are back, and its leaves sit next to each other in the
+        // pending queue, so a buffer can stay held until the ceil(leaves_in_flight / batch_size) batches behind
+        // it have run: the ring must be longer than that by the batches in flight, or the evaluation threads
+        // would wait for a free buffer that only their own next batch can release.
         struct BatchBuf {
             uint64_t* planes = nullptr;
             float *policy = nullptr, *value = nullptr;
             uint16_t *legal_idx = nullptr, *legal_cnt = nullptr;  // networks with legal_fn: policy holds probs
             uint32_t refs = 0;  // guarded by mu
-        } bufs[NBUF];
+        };
+        const uint32_t lif = std::min(std::max(cfg_.mcts.leaves_in_flight, 1u), (uint32_t)MctsPlayer<G>::MAX_IN_FLIGHT);
+        const uint32_t eval_threads = std::max(1u, cfg_.eval_threads);
+        int NBUF = (int)std::max(6u, (lif + cfg_.batch_size - 1) / cfg_.batch_size + eval_threads + 1);
+        if (!same_model_) NBUF *= 2;  // two pending queues share the ring
+        std::vector<BatchBuf> bufs((size_t)NBUF);
         // Row length of the per-leaf result: all logits, or (legal_fn) one probability per legal move.
         const bool legal = vf1_.net().legal_fn != nullptr;
         if (legal != (vf2_.net().legal_fn != nullptr)) {
@@ -500,7 +558,7 @@ class SelfPlayRunner {
         };
         {
             std::vector<std::thread> evals;
-            for (uint32_t i = 1; i < std::max(1u, cfg_.eval_threads); i++) evals.emplace_back(evaluator);
+            for (uint32_t i = 1; i < eval_threads; i++) evals.emplace_back(evaluator);
             evaluator();
             for (auto& t : evals) t.join();
         }
@@ -531,8 +589,7 @@ class SelfPlayRunner {
         MctsPlayer<G>* cur = nullptr;
         uint32_t game_idx = 0;
         bool players_switch = false;
-        std::vector<Position> history;
-        bool repetition_detected = false;
+        GameState<G> game;
         std::vector<std::pair<Position, std::vector<std::pair<Move, float>>>> pairs;
         // leaves of the current search waiting for an evaluation (one, unless mcts.leaves_in_flight > 1)
         PendingLeaf<G> pend[MctsPlayer<G>::MAX_IN_FLIGHT];
@@ -549,21 +606,6 @@ class SelfPlayRunner {
         std::string error;
         Slot(const MctsParams& p, uint64_t seed) : p1(p, seed * 2 + 1), p2(p, seed * 2 + 2) {}
     };
-
-    Status game_status(const Slot& s) const {  // ChessGame::status (chess/core.rs:431-436) / position status
-        if (s.repetition_detected) return Status::draw();
-        return s.history.back().status();
-    }
-    void play(Slot& s, Move m) {  // Game::play_single_turn (chess/core.rs:438-450)
-        Position np = s.history.back().moved(m);
-        if (G::REPETITION_LIMIT > 1) {
-            int cnt = 1;
-            for (auto& p : s.history)
-                if (p == np) cnt++;
-            if (cnt >= G::REPETITION_LIMIT) s.repetition_detected = true;
-        }
-        s.history.push_back(np);
-    }
 
     void advance(Slot& s, std::atomic<uint32_t>& next_game, uint32_t games_num, const std::string& d1, const std::string& d2,
                  std::vector<Record>* records, SelfPlayResult& res, std::mutex& out_mu) {
@@ -584,25 +626,24 @@ class SelfPlayRunner {
                     // is then the same whatever the schedule, the slot count or the sharding over processes
                     s.p1.reseed(mix64(cfg_.seed * 1000003ull + s.game_idx) * 2 + 1);
                     s.p2.reseed(mix64(cfg_.seed * 1000003ull + s.game_idx) * 2 + 2);
-                    s.history.assign(1, Position::initial());
-                    s.repetition_detected = false;
+                    s.game.reset(Position::initial());
                     s.pairs.clear();
                     s.state = Slot::NEXT_MOVE;
                     break;
                 }
                 case Slot::NEXT_MOVE: {
-                    const Status st = game_status(s);
+                    const Status st = s.game.status();
                     if (st.finished) {
                         finish_game(s, st.winner, d1, d2, records, res, out_mu);
                         s.state = Slot::IDLE;
                         break;
                     }
-                    Color player = s.history.back().turn();
+                    Color player = s.game.history.back().turn();
                     if (s.players_switch) player = opposite(player);
                     s.cur = player == PLAYER1 ? &s.p1 : &s.p2;
                     s.netid = (player == PLAYER1 || same_model_) ? 0 : 1;
                     s.search_t0 = std::chrono::steady_clock::now();
-                    s.cur->begin_search(s.history);
+                    s.cur->begin_search(s.game.history);
                     s.state = Slot::SEARCHING;
                     break;
                 }
@@ -626,7 +667,7 @@ class SelfPlayRunner {
                     break;
                 }
                 case Slot::SEARCHING: {
-                    const auto step = s.cur->advance(s.history);
+                    const auto step = s.cur->advance(s.game.history);
                     if (step == MctsPlayer<G>::NEED_EVAL) {
                         auto& vf = s.netid == 0 ? vf1_ : vf2_;
                         s.npend = s.cur->pending_count();
@@ -647,13 +688,13 @@ class SelfPlayRunner {
                         auto probs = s.cur->result();
                         metrics_.set_search(std::chrono::duration<double>(std::chrono::steady_clock::now() - s.search_t0).count());
                         Move m;
-                        if (!s.cur->choose_move(s.history, probs, m)) {
+                        if (!s.cur->choose_move(s.game.history, probs, m)) {
                             s.error = "search returned no move";
                             s.state = Slot::DONE;
                             return;
                         }
-                        s.pairs.emplace_back(s.history.back(), std::move(probs));
-                        play(s, m);
+                        s.pairs.emplace_back(s.game.history.back(), std::move(probs));
+                        s.game.play(m);
                         s.state = Slot::NEXT_MOVE;
                     }
                     break;

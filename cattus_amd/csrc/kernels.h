@@ -32,25 +32,6 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
-// ---- K1 persistent: all tower layers in one launch (see kernels.hip) ------------------------
-struct TowerLayer {
-    const void* w;      // [9][cout][cin]
-    const float* bias;  // [cout]
-    int in_buf, res_buf, out_buf;  // indices into TowerArgs::buf; res_buf < 0: no skip connection
-    int cin;
-};
-struct TowerArgs {
-    void* buf[4];              // 0: stem input [B4][64][cin0], 1..3: tower ping-pong buffers [B4][64][cout]
-    const TowerLayer* layers;  // device array [nlayers]
-    unsigned* counters;        // [board groups][nlayers][8], zeroed before every launch
-    unsigned* err;             // set to 1 if a wait timed out
-    int nlayers, cout, S;
-    int xcd_local;             // 1: hand-off through the shared L2 of one XCD (see kernels.hip), 0: agent scope
-    long long spin_budget_ticks;  // s_memrealtime ticks (100 MHz)
-};
-void launch_tower_persistent(Act act, const TowerArgs& args, uint32_t bpad, hipStream_t st, hipEvent_t ev_start = nullptr,
-                             hipEvent_t ev_stop = nullptr);
-
 // Selects the tower kernel variant (1 or 2); for A/B measurements only.
 void set_conv_impl(int v);
 

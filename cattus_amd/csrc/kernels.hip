@@ -218,11 +218,6 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
 }
-// the same with sc1: bypasses this CU's L1 and is served by the XCD's L2
-__device__ __forceinline__ void glds16_l2(const char* src, char* lds_dst) {
-    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 16);
-}
-
 template <typename T, bool HAS_RES>
 __global__ void __launch_bounds__(256, 1)
     conv3x3_mfma_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
@@ -728,350 +723,12 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     STAMP_FLUSH(wave);
 }
 
-// ------------------------------------------------------------------------------------------
-// K1 persistent: the whole 3x3 tower (stem + 2 convs per residual block) in ONE launch
-// ------------------------------------------------------------------------------------------
-//
-// Same workgroup tile, LDS map, loader/consumer roles and arithmetic as conv3x3_mfma_v2_kernel, with a
-// loop over the layers inside the kernel.  Layer l+1 of the workgroup (board group bg, cout slab cs)
-// needs layer l's output of the same 4 boards from the (cout / 64) workgroups of board group bg --
-// and from nobody else.  So there is no grid-wide barrier: after its epilogue every workgroup bumps
-// the counter of (bg, l); before loading layer l+1's activations it waits for that counter to reach
-// cout / 64.  Per layer this replaces a kernel boundary (launch ramp, end-of-kernel write-back,
-// cold prologue) by a hand-off between a few neighbouring workgroups, and the next layer's first
-// weight slabs are requested while the hand-off is still in flight.
-//
-// Hand-off protocol (cdna_hip_programming.md, Guideline 16, R1 with a counter):
-//   producer: outputs are stored write-through (sc1); every storing wave drains its stores
-//             (s_waitcnt vmcnt(0)); workgroup barrier; one lane adds 1 to the counter (relaxed, agent).
-//   consumer: one lane polls the counter (relaxed agent loads, s_sleep between polls, bounded by a
-//             wall-clock budget); then one agent-scope acquire (invalidates this CU's L1), drained;
-//             workgroup barrier; only then are the activations requested.
-// Same-XCD variant (TowerArgs::xcd_local): the workgroups of a board group have equal blockIdx % 8, which the
-// dispatcher is observed to place on one XCD, i.e. behind one L2.  Then nothing has to leave that L2:
-//   producer: plain stores (the lines stay in the XCD's L2), drained; barrier; one lane adds 1 with a
-//             non-sc1 atomic (executed in that L2) to the counter slot of ITS OWN XCC id (HW_REG_XCC_ID).
-//   consumer: polls the slot of its own XCC id with L1-bypassing loads; no L1 invalidate: the activation
-//             DMA and the skip-row loads of this kernel carry sc1 (bypass L1, served by the L2).
-// If the dispatcher ever placed a group's workgroups on different XCDs their adds would land in different
-// slots, the consumer's slot would never fill, the wait would time out and the host falls back: placement
-// decides speed, a wrong assumption about it costs one time-out, never a wrong result.
-// Correctness never depends on placement.  Progress needs the workgroups of one board group to be
-// resident together: 139 KB of LDS admits one workgroup per CU and they are dispatched in blockIdx
-// order, so the first 256 blocks always contain whole groups.  Every spin is bounded: on time-out the
-// kernel sets *err and runs on (the host then discards the result and uses the per-layer kernels).
-template <typename T>
-__global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4) tower_persistent_kernel(TowerArgs A) {
-    constexpr int KC = 128 / (int)sizeof(T);
-    typedef typename Mfma<T>::frag frag;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const bool is_loader = wave >= 4;
-    const int cout = A.cout, S = A.S;
-
-    const int nblk = gridDim.x, ncb = cout / COUT_PER_WG;
-    int logical = blockIdx.x;
-    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int cout0 = (logical % ncb) * COUT_PER_WG;
-    const int bg = logical / ncb;
-    const int b0 = bg * BOARDS_PER_WG;
-    const bool xl = A.xcd_local != 0;
-    // counter slot: this CU's XCC id (HW_REG_XCC_ID = 20, bits 3:0) in the same-XCD protocol, else slot 0
-    const unsigned slot = xl ? (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) : 0u;
-
-    if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-    // ---- consumer-only per-lane geometry (cheap; computed by every wave) ----
-    const int r = lane & 31, h = lane >> 5;
-    int ph[2], pw[2];
-    bool pvalid[2];
-#pragma unroll
-    for (int pb = 0; pb < 2; pb++) {
-        const int p = pb * 32 + r;
-        ph[pb] = p / S;
-        pw[pb] = p - ph[pb] * S;
-        pvalid[pb] = p < S * S;
-    }
-    int aaddr[4][2];
-#pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
-        const int row = cb * 32 + r;
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) aaddr[ks][cb] = V2_LDS_W + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4);
-    }
-    int opaque = 0;
-
-    for (int layer = 0; layer < A.nlayers; layer++) {
-        const TowerLayer L = A.layers[layer];
-        const T* in = reinterpret_cast<const T*>(A.buf[L.in_buf]);
-        const T* w = reinterpret_cast<const T*>(L.w);
-        T* out = reinterpret_cast<T*>(A.buf[L.out_buf]);
-        const int cin = L.cin;
-        const int nch = cin / KC;
-        const int T_total = nch * 3;
-        const uint32_t row_bytes = (uint32_t)cin * sizeof(T);
-
-        if (is_loader) {
-            // ================================ loader waves ================================
-            const int lw = wave - 4;
-            const int prow = lane >> 3, pslot = lane & 7;
-            uint32_t off_w[WPL], off_a[2][APL];
-            int dst_w[WPL], dst_a[2][APL];
-#pragma unroll
-            for (int i = 0; i < WPL; i++) {
-                const int pid = lw * WPL + i;
-                const int tap_i = pid >> 3, row = (pid & 7) * 8 + prow;
-                const int c = pslot ^ ((row >> 1) & 7);
-                off_w[i] = ((uint32_t)(tap_i * cout + row)) * row_bytes + c * 16;
-                dst_w[i] = pid * 1024;
-            }
-#pragma unroll
-            for (int g = 0; g < 2; g++)
-#pragma unroll
-                for (int i = 0; i < APL; i++) {
-                    const int id = g * 16 + lw * APL + i;
-                    const int row = id * 8 + prow;
-                    const int c = pslot ^ ((row >> 1) & 7);
-                    off_a[g][i] = (uint32_t)row * row_bytes + c * 16;
-                    dst_a[g][i] = id * 1024;
-                }
-            const char* wbase0 = reinterpret_cast<const char*>(w) + (size_t)cout0 * row_bytes;
-            const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)b0 * SLOTS * row_bytes;
-            auto issue_w = [&](int t) {
-                const int ch = t / 3, g = t - ch * 3;
-                const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)ch * 128;
-                char* dst = smem + V2_LDS_W + (t % 3) * V2_SLAB;
-#pragma unroll
-                for (int i = 0; i < WPL; i++) glds16(src + off_w[i], dst + dst_w[i]);
-            };
-            auto issue_a = [&](int ch, int g) {
-                const char* src = abase0 + (size_t)ch * 128;
-                char* dst = smem + V2_LDS_ACT + (ch & 1) * 32768;
-                if (xl) {
-#pragma unroll
-                    for (int i = 0; i < APL; i++) glds16_l2(src + off_a[g][i], dst + dst_a[g][i]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
-                }
-            };
-
-            // weights do not depend on the other workgroups: request them while the hand-off completes
-            issue_w(0);
-            issue_w(1);
-            asm volatile("s_barrier" ::: "memory");  // barrier A: this layer's input is published and acquired
-            issue_a(0, 0);
-            issue_a(0, 1);
-            int pending = 0;  // first step: everything issued so far must have landed
-            for (int t = 0; t < T_total; t++) {
-                if (pending == WPL + APL) wait_vm_barrier<WPL + APL>();
-                else if (pending == WPL) wait_vm_barrier<WPL>();
-                else wait_vm_barrier<0>();
-                pending = 0;
-                const int ch = t / 3, g = t - ch * 3;
-                if (t + 2 < T_total) {
-                    issue_w(t + 2);
-                    pending += WPL;
-                }
-                if (g < 2 && ch + 1 < nch) {
-                    issue_a(ch + 1, g);
-                    pending += APL;
-                }
-            }
-            wait_vm_barrier<0>();  // barrier P: epilogue done, LDS free for the next layer
-            continue;
-        }
-
-        // ================================ consumer waves ================================
-        if (layer > 0 && wave == 0) {
-            // wait until every workgroup of this board group has published the previous layer
-            unsigned* cnt = A.counters + ((size_t)bg * A.nlayers + (layer - 1)) * 8 + slot;
-            if (lane == 0) {
-                const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ncb) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > A.spin_budget_ticks) {
-                        __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            if (!xl) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier A
-
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-
-        constexpr int AHEAD = 2, RING = 3;
-        for (int ch = 0; ch < nch; ch++) {
-            const int abase = V2_LDS_ACT + (ch & 1) * 32768 + wave * 8192;
-#pragma unroll
-            for (int g = 0; g < 3; g++) {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                asm volatile("" : "+v"(opaque));
-                const int wslab = g * V2_SLAB;
-                int baddr[3][2][4];
-#pragma unroll
-                for (int dxi = 0; dxi < 3; dxi++)
-#pragma unroll
-                    for (int pb = 0; pb < 2; pb++) {
-                        const int hh = ph[pb] + (g - 1) + opaque, ww = pw[pb] + dxi - 1;
-                        const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
-                        const int q = hh * S + ww;
-                        const int rowa = ok ? abase + q * 128 : V2_LDS_ZERO;
-                        const int x0 = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
-#pragma unroll
-                        for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
-                    }
-                frag fa[RING][2], fb[RING][2];
-                auto load_stage = [&](int i, frag (&a)[2], frag (&b)[2]) {
-                    const int dxi = i >> 2, ks = i & 3;
-#pragma unroll
-                    for (int cb = 0; cb < 2; cb++)
-                        a[cb] = *reinterpret_cast<const frag*>(smem + aaddr[ks][cb] + (wslab + dxi * 8192));
-#pragma unroll
-                    for (int pb = 0; pb < 2; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][ks]);
-                };
-#pragma unroll
-                for (int i = 0; i < AHEAD; i++) load_stage(i, fa[i % RING], fb[i % RING]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 * AHEAD, 0);
-#pragma unroll
-                for (int i = 0; i < 12; i++) {
-                    if (i + AHEAD < 12) load_stage(i + AHEAD, fa[(i + AHEAD) % RING], fb[(i + AHEAD) % RING]);
-#pragma unroll
-                    for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-                        for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
-                    if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-                }
-            }
-        }
-
-        // ---- epilogue: as in conv3x3_mfma_v2_kernel, with write-through (sc1) output stores ----
-        {
-            const bool has_res = L.res_buf >= 0;
-            const T* res = has_res ? reinterpret_cast<const T*>(A.buf[L.res_buf]) : out;
-            const size_t board = (size_t)(b0 + wave);
-            const int tile0 = V2_LDS_ACT + wave * 8192;
-            const int prow = lane >> 3, cg = lane & 7;
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-            const size_t act_bytes_total = (size_t)(gridDim.x / ncb) * BOARDS_PER_WG * SLOTS * cout * sizeof(T);
-            auto rsrc_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(res), 0, (int)act_bytes_total, 0x00020000);
-            auto load_res = [&](int i0, T (&rv)[4][8]) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const size_t off = (board * SLOTS + (i0 + i) * 8 + prow) * (size_t)cout + cout0 + cg * 8;
-                    const unsigned boff = (unsigned)(off * sizeof(T));
-                    u32x4* dst = reinterpret_cast<u32x4*>(rv[i]);
-                    if (xl) {  // sc1: not from this CU's L1, which nothing has invalidated
-                        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff, 0, 16);
-                        if (sizeof(T) == 4) dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff + 16, 0, 16);
-                    } else {
-                        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff, 0, 0);
-                        if (sizeof(T) == 4) dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, boff + 16, 0, 0);
-                    }
-                }
-            };
-            T resv[4][8];
-            if (has_res) load_res(0, resv);  // skip rows of the first half, requested before the transpose
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last fragment reads are done before the staging writes
-#pragma unroll
-            for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-                for (int pb = 0; pb < 2; pb++)
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const int co = cout0 + cb * 32 + g * 8 + h * 4;
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(L.bias + co);
-                        f32x4 v;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
-                        const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
-                        *reinterpret_cast<f32x4*>(smem + tile0 + pb * 32768 + r * 256 + slot * 16) = v;
-                    }
-            // buffer descriptor for the output stores (aux 16 = sc1 = write-through)
-            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)act_bytes_total, 0x00020000);
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                if (half == 1 && has_res) load_res(4, resv);
-#pragma unroll
-                for (int ii = 0; ii < 4; ii++) {
-                    const int i = half * 4 + ii;
-                    const int px = i * 8 + prow, pb = px >> 5, rr = px & 31;
-                    const char* rowp = smem + tile0 + pb * 32768 + rr * 256;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (rr & 7)) << 4));
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (rr & 7)) << 4));
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const size_t off = (board * SLOTS + px) * (size_t)cout + cout0 + cg * 8;
-                    if (has_res) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) v[j] = v[j] + (float)resv[ii][j];
-                    }
-                    const bool valid = px < S * S;
-                    T ov[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        float y = v[j] > 0.0f ? v[j] : 0.0f;
-                        if (!valid) y = 0.0f;
-                        ov[j] = (T)y;
-                    }
-                    const unsigned boff = (unsigned)(off * sizeof(T));
-                    if (xl) {  // plain: the line stays in this XCD's L2 for the next layer's readers
-                        __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[0], rsrc, boff, 0, 0);
-                        if (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[1], rsrc, boff + 16, 0, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[0], rsrc, boff, 0, 16);
-                        if (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<u32x4*>(ov)[1], rsrc, boff + 16, 0, 16);
-                    }
-                }
-            }
-        }
-        // publish: every storing wave drains its write-through stores, the workgroup meets, one lane signals
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier P
-        if (wave == 0 && lane == 0) {
-            unsigned* cnt = A.counters + ((size_t)bg * A.nlayers + layer) * 8 + slot;
-            if (xl) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // in this XCD's L2
-            else __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 // The opt-in for > 64 KiB of dynamic LDS is a per-device function attribute: set it once per device.
 static bool first_use_on_device(std::atomic<uint64_t>& mask) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     return (mask.fetch_or(bit) & bit) == 0;
-}
-
-void launch_tower_persistent(Act act, const TowerArgs& args, uint32_t bpad, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const dim3 grid((bpad / BOARDS_PER_WG) * (args.cout / COUT_PER_WG)), block(256 + 64 * NLOAD);
-    static std::atomic<uint64_t> attr_bf16{0}, attr_f32{0};
-    if (act == Act::BF16) {
-        if (first_use_on_device(attr_bf16)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_persistent_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);
-        }
-        hipExtLaunchKernelGGL((tower_persistent_kernel<__bf16>), grid, block, V2_LDS_TOTAL, st, ev_start, ev_stop, 0, args);
-    } else {
-        if (first_use_on_device(attr_f32)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_persistent_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);
-        }
-        hipExtLaunchKernelGGL((tower_persistent_kernel<float>), grid, block, V2_LDS_TOTAL, st, ev_start, ev_stop, 0, args);
-    }
 }
 
 #ifdef CATTUS_STAMPS

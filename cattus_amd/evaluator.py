@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "cattus_hip_eval_device",
     "cattus_hip_eval_device_lane",
     "cattus_hip_eval_legal",
+    "cattus_hip_lane_stream",
     "cattus_hip_submit",
     "cattus_hip_wait",
     "cattus_hip_flush",
@@ -102,6 +103,7 @@ def load_library():
     L.cattus_hip_eval.argtypes = [vp, u64p, C.c_uint32, f32p, f32p]
     L.cattus_hip_eval_device.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
     L.cattus_hip_eval_device_lane.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp]
+    L.cattus_hip_lane_stream.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     u16p = C.POINTER(C.c_uint16)
     L.cattus_hip_eval_legal.argtypes = [vp, u64p, C.c_uint32, u16p, u16p, C.c_uint32, f32p, f32p]
     L.cattus_hip_submit.argtypes = [vp, u64p, C.POINTER(C.c_uint64)]
@@ -238,8 +240,15 @@ class HipEvaluator:
         return [(policy[i], float(value[i])) for i in range(len(value))]
 
     def eval_device(self, d_planes: int, n: int, d_policy: int, d_value: int, stream: int = 0, lane: int = 0):
-        """Asynchronous evaluation on raw device pointers (all buffers resident in HBM)."""
+        """Asynchronous evaluation on raw device pointers (all buffers resident in HBM), enqueued on
+        ``stream`` (a hipStream_t handle; 0 is HIP's legacy default stream)."""
         _check(self._lib.cattus_hip_eval_device_lane(self._h, lane, d_planes, n, d_policy, d_value, stream))
+
+    def lane_stream(self, lane: int = 0) -> int:
+        """Handle of the lane's own stream."""
+        st = C.c_void_p()
+        _check(self._lib.cattus_hip_lane_stream(self._h, lane, C.byref(st)))
+        return st.value or 0
 
     # -- leaf server (Batcher::apply replacement, util/batch.rs:49-177) ---------------------
     def submit(self, planes_one) -> int:

@@ -40,6 +40,8 @@ ABI_SYMBOLS = [
     "cattus_sp_last_error",
     "cattus_sp_stub_net",
     "cattus_sp_trace_game",
+    "cattus_sp_trace_game_ex",
+    "cattus_sp_play_moves",
     "cattus_sp_pos_new",
     "cattus_sp_pos_free",
     "cattus_sp_pos_status",
@@ -138,6 +140,9 @@ def load_library():
     L.cattus_sp_last_error.restype = C.c_char_p
     L.cattus_sp_trace_game.argtypes = [C.c_int, C.POINTER(SpConfig), vp, vp, C.c_uint32, vp, C.c_size_t]
     L.cattus_sp_trace_game.restype = C.c_int64
+    L.cattus_sp_trace_game_ex.argtypes = [C.c_int, C.POINTER(SpConfig), vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_size_t]
+    L.cattus_sp_trace_game_ex.restype = C.c_int64
+    L.cattus_sp_play_moves.argtypes = [C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.cattus_sp_pos_new.argtypes = [C.c_int, C.c_char_p]
     L.cattus_sp_pos_new.restype = vp
     L.cattus_sp_pos_free.argtypes = [vp]
@@ -352,14 +357,19 @@ def run_self_play(game: str, cfg: SpConfig, net1: Net, net2: Net | None, games_n
         L.cattus_sp_result_free(res)
 
 
-def trace_game(game: str, cfg: SpConfig, net: Net, max_plies: int = 512):
-    """One self-play game; returns [(chosen nn_idx, [(nn_idx, visits), ...]), ...] per ply."""
+def trace_game(game: str, cfg: SpConfig, net: Net, max_plies: int = 512, forced=(), search_from: int = 0):
+    """One self-play game; returns [(chosen nn_idx, [(nn_idx, visits), ...]), ...] per searched ply.
+
+    forced: policy indices played at plies 0.. instead of the search's choice (the choice is still
+    reported); plies below search_from are played without a search."""
     L = load_library()
     info = game_info(game)
     net.bind_words(info["planes"] * info["plane_words"])
     cap = 2 + max_plies * (2 + 2 * 256)
     buf = np.zeros(cap, dtype=np.uint32)
-    n = L.cattus_sp_trace_game(GAMES[game], C.byref(cfg), net.fn_addr, net.ctx, max_plies, buf.ctypes.data, cap)
+    fm = np.ascontiguousarray(list(forced), dtype=np.uint16)
+    n = L.cattus_sp_trace_game_ex(GAMES[game], C.byref(cfg), net.fn_addr, net.ctx, max_plies, fm.ctypes.data if len(fm) else None,
+                                  len(fm), search_from, buf.ctypes.data, cap)
     if n < 0:
         raise RuntimeError("trace_game failed: " + _err())
     plies, w, out = int(buf[0]), 1, []
@@ -369,6 +379,17 @@ def trace_game(game: str, cfg: SpConfig, net: Net, max_plies: int = 512):
         out.append((chosen, pairs))
         w += 2 + 2 * k
     return out
+
+
+def play_moves(game: str, moves) -> tuple:
+    """Game::play_single_turn over policy-index moves from the initial position -> (status, plies played);
+    status 'ongoing' or the winner +1 / -1 / 0 (0 also for a draw by repetition)."""
+    mv = np.ascontiguousarray(list(moves), dtype=np.uint16)
+    played = C.c_uint32()
+    st = load_library().cattus_sp_play_moves(GAMES[game], mv.ctypes.data if len(mv) else None, len(mv), C.byref(played))
+    if st <= -100:
+        raise ValueError(_err())
+    return ("ongoing" if st == 2 else st), played.value
 
 
 class Position:

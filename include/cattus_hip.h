@@ -85,9 +85,12 @@ int cattus_hip_eval(cattus_eval* e, const uint64_t* planes, uint32_t n, float* p
 int cattus_hip_eval_legal(cattus_eval* e, const uint64_t* planes, uint32_t n, const uint16_t* legal_idx,
                           const uint16_t* legal_count, uint32_t legal_stride, float* probs, float* value);
 
-/* Same with every buffer already resident in device memory (HBM) and asynchronous on `stream`
- * (a hipStream_t; NULL = the evaluator's own stream).  Used by bench.py so that the timed
- * region excludes PCIe. */
+/* Same with every buffer already resident in device memory (HBM) and asynchronous on `stream`, a
+ * hipStream_t taken as HIP takes it: NULL is the legacy default stream.  All work of the call is enqueued
+ * on that stream and nowhere else, so the caller orders it (and reads d_policy / d_value) with the
+ * stream's own means: later work on the same stream, an event, or hipStreamSynchronize.  The evaluator's
+ * intermediate buffers belong to a lane (below): two calls on one lane must not overlap on the device.
+ * Used by bench.py so that the timed region excludes PCIe. */
 int cattus_hip_eval_device(cattus_eval* e, const uint64_t* d_planes, uint32_t n, float* d_policy,
                            float* d_value, void* stream);
 
@@ -99,6 +102,9 @@ int cattus_hip_eval_device(cattus_eval* e, const uint64_t* d_planes, uint32_t n,
 #define CATTUS_HIP_LANES 2
 int cattus_hip_eval_device_lane(cattus_eval* e, uint32_t lane, const uint64_t* d_planes, uint32_t n,
                                 float* d_policy, float* d_value, void* stream);
+/* The lane's own non-blocking stream (the one cattus_hip_eval uses for that lane), for callers of the
+ * device entry points that have no stream of their own. */
+int cattus_hip_lane_stream(cattus_eval* e, uint32_t lane, void** stream);
 
 /* Leaf-batching server, the replacement of Batcher::apply (engine/src/util/batch.rs:49-177):
  * submit copies one leaf's planes and returns a ticket; wait blocks until that leaf's batch ran

@@ -110,6 +110,19 @@ int cattus_sp_stub_net(void* ctx, const uint64_t* planes, uint32_t n, float* pol
 int64_t cattus_sp_trace_game(int game, const cattus_sp_config* cfg, cattus_net_eval_fn net, void* ctx, uint32_t max_plies,
                              uint32_t* out, size_t cap);
 
+/* The same with a forced line: plies < n_forced play forced[ply] (policy indices; must be legal) whatever the
+ * search chose, and plies < search_from are played without a search at all (an opening).  Every searched ply
+ * is still reported with the move the search chose.  max_plies bounds the searched plies.  Used to search the
+ * same positions with two evaluators, and to put a repetition in front of a search. */
+int64_t cattus_sp_trace_game_ex(int game, const cattus_sp_config* cfg, cattus_net_eval_fn net, void* ctx, uint32_t max_plies,
+                                const uint16_t* forced, uint32_t n_forced, uint32_t search_from, uint32_t* out, size_t cap);
+
+/* Game::play_single_turn over a list of moves (policy indices) from the initial position, with the game-level
+ * rules on top of the position's: chess threefold repetition (chess/core.rs:438-450).  Stops at the first
+ * finished state.  Returns 2 = ongoing, +1 / -1 / 0 = winner / draw, <= -100 = error; *plies_played = moves
+ * applied. */
+int cattus_sp_play_moves(int game, const uint16_t* moves, uint32_t n, uint32_t* plies_played);
+
 /* ---- position handles (rule tests) ---------------------------------------------------------- */
 typedef struct cattus_pos cattus_pos;
 /* str: NULL = initial position; ttt "xo_..."+turn, hex "reb..."+turn (test_util.rs:7-66), chess FEN */

@@ -7,6 +7,7 @@ library (cattus_amd/csrc/host) is cross-checked on small games:
   NNetwork::evaluate / flip / softmax   engine/src/net/mod.rs:74-119,158-182
   ValueFuncCache                  engine/src/mcts/cache.rs:31-75 (as a dict; FIFO irrelevant at test sizes)
   tic-tac-toe, Hex rules          engine/src/ttt/core.rs, engine/src/hex/core.rs
+  repetition (in search, in game) engine/src/mcts/mod.rs:133-154, engine/src/chess/core.rs:438-450
   self-play game loop             training/self-play/src/self_play.rs:179-217
 
 The search tree mimics petgraph's adjacency lists literally: every node keeps its outgoing edges in
@@ -169,6 +170,63 @@ def make_hex(n: int):
     return Hex
 
 
+_CHESS_NAMES = None
+
+
+def make_chess():
+    """Chess for the search restatement.  The RULES (legal moves in the reference's order, make-move, status,
+    flip, planes) come from the host library's position handles -- they have their own tests
+    (tests/test_host_rules.py: perft, the reference's mate / fifty-move / flip cases); what is restated
+    independently here is everything the search and the game loop do WITH positions: equality that ignores
+    the fifty-move counter (chess/core.rs:288-305; the FEN without counters is the key), the in-search
+    repetition rule (mcts/mod.rs:133-154) and the game-level threefold rule (chess/core.rs:438-450)."""
+    from cattus_amd import selfplay as sp
+
+    global _CHESS_NAMES
+    if _CHESS_NAMES is None:
+        names = sp.chess_nn_moves()
+        _CHESS_NAMES = (names, {nm: i for i, nm in enumerate(names)})
+    names, index = _CHESS_NAMES
+
+    class Chess:
+        MOVES, REPETITION_LIMIT = 1880, 3
+
+        def __init__(self, h=None):
+            self.h = h if h is not None else sp.Position("chess")
+            self.turn = 1 if self.h.turn() == 0 else 2
+            self._legal = None
+
+        def key(self):
+            return str(self.h)
+
+        def status(self):
+            st = self.h.status()
+            if st == "ongoing":
+                return ("ongoing", None)
+            return ("finished", {1: 1, -1: 2, 0: None}[st])
+
+        def legal_moves(self):
+            if self._legal is None:
+                self._legal = [nn for _, nn in self.h.legal_moves()]
+            return list(self._legal)
+
+        def moved(self, m):
+            return Chess(self.h.moved(self.legal_moves().index(m)))
+
+        def flipped(self):
+            return Chess(self.h.flipped())
+
+        @staticmethod
+        def flip_move(m):  # mirror the ranks (chess/core.rs:40-53)
+            nm = names[m]
+            return index[nm[0] + str(9 - int(nm[1])) + nm[2] + str(9 - int(nm[3])) + nm[4:]]
+
+        def planes(self):
+            return [int(w) for w in self.h.planes().reshape(-1)]
+
+    return Chess
+
+
 # ----------------------------------------------------------------------------- value function
 
 
@@ -240,13 +298,29 @@ class MctsPlayer:
             path.append(best)
             node = self.g.edges[best]["dst"]
 
+    def _repetition(self, history, path):
+        """detect_repetition (mcts/mod.rs:133-154): positions of the game history, then the targets of the
+        path's edges; true as soon as one of them has been counted REPETITION_LIMIT times."""
+        limit = getattr(type(history[-1]), "REPETITION_LIMIT", None)
+        if not limit or limit <= 1:
+            return False
+        counts = {}
+        for p in list(history) + [self.g.pos[self.g.edges[e]["dst"]] for e in path]:
+            k = p.key()
+            counts[k] = counts.get(k, 0) + 1
+            if counts[k] >= limit:
+                return True
+        return False
+
     def _develop(self, history):
         assert self.sim_num > 1
         for _ in range(self.sim_num):
             path = self._select()
             leaf = self.root if not path else self.g.edges[path[-1]]["dst"]
             st = self.g.pos[leaf].status()
-            if st[0] == "finished":
+            if self._repetition(history, path):
+                score = F(0)
+            elif st[0] == "finished":
                 score = F({1: 1.0, 2: -1.0, None: 0.0}[st[1]])
             else:
                 per_move, score = self.vf.evaluate(self.g.pos[leaf])
@@ -310,17 +384,31 @@ class MctsPlayer:
         return best[0]
 
 
-def trace_game(game_cls, sim_num, explore_factor, max_plies=512, net=stub_net):
+def trace_game(game_cls, sim_num, explore_factor, max_plies=512, net=stub_net, forced=(), search_from=0):
     """One self-play game as a reference worker plays it (two persistent players, temperature 0).
-    Returns [(chosen move, [(move, visits), ...]), ...] per ply, moves as nn indices."""
+    Returns [(chosen move, [(move, visits), ...]), ...] per searched ply, moves as nn indices.
+    forced / search_from as cattus_sp_trace_game_ex: plies < len(forced) play forced[ply], plies <
+    search_from are not searched.  The game ends on the position's status or, for games with a repetition
+    limit, when a position has occurred that many times (Game::play_single_turn, chess/core.rs:438-450)."""
     vf = NetValueFunction(net, game_cls.MOVES)
     p1 = MctsPlayer(sim_num, explore_factor, vf)
     p2 = MctsPlayer(sim_num, explore_factor, vf)
-    history, out = [game_cls()], []
-    while len(out) < max_plies and history[-1].status()[0] == "ongoing":
-        cur = p1 if history[-1].turn == 1 else p2
-        visits, probs = cur.calc_moves_probabilities(history)
-        m = MctsPlayer.choose_greedy(probs)
-        out.append((m, visits))
+    history, out, ply = [game_cls()], [], 0
+    limit = getattr(game_cls, "REPETITION_LIMIT", None)
+    seen, repetition = {history[0].key(): 1}, False
+    while len(out) < max_plies and not repetition and history[-1].status()[0] == "ongoing":
+        m = forced[ply] if ply < len(forced) else None
+        if ply >= search_from:
+            cur = p1 if history[-1].turn == 1 else p2
+            visits, probs = cur.calc_moves_probabilities(history)
+            chosen = MctsPlayer.choose_greedy(probs)
+            out.append((chosen, visits))
+            if m is None:
+                m = chosen
         history.append(history[-1].moved(m))
+        k = history[-1].key()
+        seen[k] = seen.get(k, 0) + 1
+        if limit and seen[k] >= limit:
+            repetition = True
+        ply += 1
     return out, vf.evals

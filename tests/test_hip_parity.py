@@ -203,28 +203,6 @@ def test_full_size_chess_20x256_batch_256():
     assert agree >= 0.9, agree
 
 
-@pytest.mark.parametrize("mode", ["persistent", "persistent-xcd"])
-def test_persistent_tower_equals_per_layer_launches(monkeypatch, mode):
-    """CATTUS_TOWER=persistent runs the whole tower in one launch with workgroup-to-workgroup hand-offs
-    (agent-scope release/acquire; `persistent-xcd`: through the shared L2 of one XCD, checked by XCC id);
-    results must be bit-identical to the per-layer kernels in both dtypes."""
-    d = NetDesc(**CHESS, blocks=6, filters=256, vhc=8, phc=8)
-    blob = seeded_blob(d, 11)
-    planes = synth.random_chess_planes(256, 11)
-    for dtype in ("f32", "bf16"):
-        monkeypatch.delenv("CATTUS_TOWER", raising=False)
-        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype) as ev:
-            p0, v0 = ev.eval(planes)
-        monkeypatch.setenv("CATTUS_TOWER", mode)
-        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype) as ev:
-            for n in (256, 37, 4, 256, 255):
-                p1, v1 = ev.eval(planes[:n])
-                assert (p1 == p0[:n]).all() and (v1 == v0[:n]).all()
-            for _ in range(20):  # repeated passes reuse the ping-pong buffers: stale cache lines would show
-                p1, v1 = ev.eval(planes)
-                assert (p1 == p0).all() and (v1 == v0).all()
-
-
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_eval_legal_softmax_bit_exact_vs_restatement(dtype):
     """cattus_hip_eval_legal = cattus_hip_eval + calc_moves_probs (net/mod.rs:100-119) on the device:
@@ -328,3 +306,20 @@ def test_device_pointer_entry_points_and_lanes_agree_with_host_entry_point():
             assert (pol.cpu().numpy() == want_p).all() and (val.cpu().numpy() == want_v).all()
         with pytest.raises(CattusHipError):
             ev.eval_device(d_planes.data_ptr(), 96, outs[0][0].data_ptr(), outs[0][1].data_ptr(), 0, lane=2)
+        # Stream ordering alone is enough (no device-wide synchronize): the work runs on the caller's stream,
+        # also when that is the legacy default stream (handle 0), and on the lane's own stream.
+        pol = torch.zeros((96, d.moves), dtype=torch.float32, device=dev)
+        val = torch.zeros((96,), dtype=torch.float32, device=dev)
+        s = streams[0]
+        ev.eval_device(d_planes.data_ptr(), 96, pol.data_ptr(), val.data_ptr(), s.cuda_stream, lane=0)
+        with torch.cuda.stream(s):
+            got = pol.clone()
+        s.synchronize()
+        assert (got.cpu().numpy() == want_p).all()
+        pol.zero_()
+        torch.cuda.synchronize()
+        ev.eval_device(d_planes.data_ptr(), 96, pol.data_ptr(), val.data_ptr(), 0, lane=1)
+        got = pol.clone()  # torch's current stream is the default stream: ordered behind the evaluation
+        torch.cuda.default_stream(dev).synchronize()
+        assert (got.cpu().numpy() == want_p).all()
+        assert ev.lane_stream(0) != 0 and ev.lane_stream(0) != ev.lane_stream(1)

@@ -235,3 +235,69 @@ def test_leaves_in_flight_fills_batches_and_stays_schedule_independent(game):
         legal = e.probs >= 0
         assert legal.sum() >= 1 and abs(e.probs[legal].sum() - 1) < 1e-4
     assert a["player1_wins"] + a["player2_wins"] + a["draws"] == 4
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("batch,lif", [(1, 8), (2, 16), (3, 16)])
+def test_small_batches_with_many_leaves_in_flight_do_not_stall(batch, lif):
+    """One slot's leaves may outnumber a whole fixed-size ring of batch buffers (batch_size 1 is the
+    make_config default): the ring is sized from the configuration, so the run completes and gives the
+    games of a roomy schedule."""
+    base = dict(sim_num=40, cache_size=100000, concurrent_games=4, leaves_in_flight=lif)
+    ref = sp.run_self_play("hex5", _cfg(**base, threads=2, batch_size=64), sp.Net.stub("hex5"), None, 4)
+    got = sp.run_self_play("hex5", _cfg(**base, threads=2, batch_size=batch), sp.Net.stub("hex5"), None, 4)
+    assert (got["record_meta"] == ref["record_meta"]).all() and (got["record_bytes"] == ref["record_bytes"]).all()
+
+
+def test_config_validation_follows_the_reference_asserts():
+    """TemperaturePolicy::scheduled and MctsPlayer::new assert these (mcts/mod.rs:106-110,470-474); the C ABI
+    reports them instead of clamping."""
+    net = sp.Net.stub("tictactoe")
+    bad = _cfg()
+    bad.temperature_count = 0
+    with pytest.raises(RuntimeError, match="temperature_count"):
+        sp.run_self_play("tictactoe", bad, net, None, 2)
+    bad = _cfg()
+    bad.temperature_count = 9
+    with pytest.raises(RuntimeError, match="temperature_count"):
+        sp.run_self_play("tictactoe", bad, net, None, 2)
+    with pytest.raises(RuntimeError, match="strictly increasing"):
+        sp.run_self_play("tictactoe", _cfg(temperature_policy=[(5, 1.0), (5, 0.5), (9999, 0.0)]), net, None, 2)
+    with pytest.raises(RuntimeError, match=">= 0"):
+        sp.run_self_play("tictactoe", _cfg(temperature_policy=[(5, -1.0), (9999, 0.0)]), net, None, 2)
+    with pytest.raises(RuntimeError, match="epsilon"):
+        sp.run_self_play("tictactoe", _cfg(prior_noise_epsilon=1.5), net, None, 2)
+    with pytest.raises(RuntimeError, match="temperature_count"):
+        sp.trace_game("tictactoe", bad, net)
+    # the last entry's threshold is unused (only its temperature is): it need not be increasing
+    sp.run_self_play("tictactoe", _cfg(temperature_policy=[(5, 1.0), (0, 0.0)]), net, None, 2)
+
+
+def test_cache_is_one_fifo_of_max_size():
+    """ValueFuncCache keeps ONE deque of max_size positions (mcts/cache.rs:62-70).  Sequential search, one
+    thread: the hit / miss counters are then a pure function of the evaluation order, and they must equal a
+    replay of that order through a plain FIFO of the same size."""
+    seen = []
+
+    def net(planes):
+        seen.extend(p.tobytes() for p in planes)
+        return _hashed_logits(planes, 25)
+
+    for size in (1, 7, 50):
+        seen.clear()
+        res = sp.run_self_play("hex5", _cfg(sim_num=30, cache_size=size), sp.Net.python(net), None, 2)
+        assert res["cache_misses"] == res["node_evals"] == len(seen)
+        # replay: every network call was a miss and inserted its position (planes identify the flipped position)
+        from collections import deque
+
+        fifo, live = deque(), set()
+        for key in seen:
+            if key in live:
+                raise AssertionError("a cached position went to the network")
+            while len(fifo) >= size:
+                live.discard(fifo.popleft())
+            fifo.append(key)
+            live.add(key)
+        big = sp.run_self_play("hex5", _cfg(sim_num=30, cache_size=100000), sp.Net.python(net), None, 2)
+        assert (big["record_bytes"] == res["record_bytes"]).all()  # results never depend on the cache
+        assert big["cache_misses"] <= res["cache_misses"]
