@@ -7,6 +7,15 @@ launches -> policy/value heads -> logits + values in HBM.  ``value`` is leaves e
 second summed over all ranks (weak scaling: every GPU runs its own batch stream, as self-play
 games shard across GPUs with no collective on the evaluation path).
 
+Beside the headline (bf16 tower) the same JSON line carries
+  f32                     the same steps on the exact-f32 tower (the reference's precision), with its own roofline
+  bf16_search_agreement   what the bf16 tower does to the SEARCH: 800-sim searches of the same positions with
+                          both towers (cattus_amd/agreement.py)
+  selfplay                BASELINE config 3 end to end: C++ search at 800 sims/move feeding this GPU (bounded sample)
+  selfplay_full_games     whole games at a reduced simulation count (a measured games/hour)
+  selfplay_config4        BASELINE config 4's shape: 64 concurrent games per GPU, records pooled over RCCL in the timed path
+  cpu_baseline            the CPU path on this host's cores: evaluator (oracle network) and search + oracle network
+
     python bench.py                       # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -38,7 +47,13 @@ WORKLOADS = {
     "chess20x256_b512": dict(game="chess", blocks=20, filters=256, vhc=8, phc=8, batch=512, seed=2),
     "chess20x256_b1024": dict(game="chess", blocks=20, filters=256, vhc=8, phc=8, batch=1024, seed=2),
     "chess20x256_b128": dict(game="chess", blocks=20, filters=256, vhc=8, phc=8, batch=128, seed=2),
+    # the reference's own configured nets (training/config/*.yaml): 7x16 and 5x8 filters
+    "chess7x16": dict(game="chess", blocks=7, filters=16, vhc=8, phc=8, batch=256, seed=4),
+    "hex7_7x16": dict(game="hex7", blocks=7, filters=16, vhc=16, phc=16, batch=128, seed=5),
 }
+
+SELFPLAY_SETTINGS = dict(temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25)
+SELFPLAY_SETTINGS_TEXT = "temperature 1.0 for 30 moves then 0, Dirichlet noise 0.03/0.25, cache 1e6, batch 256 (training/config/chess_dev.yaml:52-68)"
 
 
 def make_workload(name: str):
@@ -55,36 +70,86 @@ def make_workload(name: str):
     return d, seeded_blob(d, w["seed"]), planes
 
 
-def cpu_baseline(blob, planes, budget_s: float = 20.0):
-    """The oracle (a plain C port of the same arithmetic) timed on this host's cores, on a bounded
-    sample of the same workload."""
+# ------------------------------------------------------------------------------------------ CPU baseline
+
+
+def cpu_baseline(blob, planes, budget_s: float = 12.0):
+    """The CPU path on this host, bounded samples.  `evaluator`: the oracle network (oracle/oracle_net.c, a plain C
+    port of the same arithmetic, OpenMP over leaves) on the bench leaves, on every CPU this process may use
+    (cgroup quota, not the affinity mask) and on one thread.  `selfplay`: the C++ search of this repository with
+    the oracle network behind its network callback (no Python in the loop), one search thread per CPU -- the
+    reference's threading model -- on hex7 6x64 and chess 20x256, games cut after a few plies so that each
+    sample costs about `budget_s`.  The reference's own Rust path cannot be built on this box (no Rust toolchain)."""
+    from cattus_amd import selfplay as sp
+    from cattus_amd.weights import NetDesc, hex_game, seeded_blob
     from oracle import oracle
 
+    cores = oracle.default_threads()
     net = oracle.OracleNet(blob)
-    threads = oracle.default_threads()
-    n = min(len(planes), threads)
-    t0 = time.perf_counter()
-    net.forward(planes[:n], threads=threads)
-    dt = time.perf_counter() - t0
-    # second, larger sample sized to the remaining budget
-    n2 = int(min(len(planes), max(n, (budget_s - dt) * n / dt * 0.8)))
-    n2 = max(threads, n2 // threads * threads)
-    t0 = time.perf_counter()
-    net.forward(planes[:n2], threads=threads)
-    dt = time.perf_counter() - t0
-    return {
-        "value": n2 / dt,
+
+    def timed(n, threads):
+        t0 = time.perf_counter()
+        net.forward(planes[:n], threads=threads)
+        return time.perf_counter() - t0
+
+    timed(min(len(planes), cores), cores)  # warm-up: thread pool, scratch buffers
+    dt1 = timed(1, 1)
+    n1 = int(max(1, min(8, 2.0 / dt1)))
+    dt1 = timed(n1, 1)
+    n = cores
+    dt = timed(n, cores)
+    n = int(min(len(planes), max(cores, (budget_s * n / dt) // cores * cores)))
+    dt = timed(n, cores)
+    out = {
+        "value": n / dt,
         "unit": "node-evals/s",
-        "cores": threads,
+        "cores": cores,
         "kind": "port",
-        "sample": f"{n2} of the {len(planes)} bench leaves, oracle/oracle_net.c f32 on {threads} threads, {dt:.1f} s",
+        "sample": f"{n} of the {len(planes)} bench leaves, oracle/oracle_net.c f32 on {cores} threads, {dt:.1f} s",
+        "evaluator": {"value": n / dt, "cores": cores, "one_thread": n1 / dt1, "one_thread_sample": f"{n1} leaves, {dt1:.1f} s"},
     }
+
+    # ---- the path: search + network, one search thread per CPU, each blocking on its own leaf (batch_size 1)
+    def path(game, oblob, oplanes, words, sims, settings):
+        onet = oracle.OracleNet(oblob)
+        onet.forward(oplanes[:cores], threads=cores)
+        t0 = time.perf_counter()
+        onet.forward(oplanes[: 4 * cores], threads=cores)
+        rate = 4 * cores / (time.perf_counter() - t0)
+        games = max(2, cores // 2 * 2)
+        # bounded sample: every game is cut after `plies` plies so that the leg costs about budget_s at that rate
+        plies = int(max(1, min(64, budget_s * rate / (games * sims))))
+        fn, ctx, keep = onet.callback(plane_words=words, threads=1)
+        cfg = sp.make_config(sim_num=sims, batch_size=1, threads=cores, concurrent_games=games, cache_size=1000000, eval_threads=cores,
+                             max_game_plies=plies, seed=1, **settings)
+        t0 = time.perf_counter()
+        res = sp.run_self_play(game, cfg, sp.Net.raw(fn, ctx, keep), None, games, keep_records=False)
+        secs = time.perf_counter() - t0
+        return {"node_evals_per_sec": res["node_evals"] / secs, "plies_per_sec": res["positions"] / secs, "games": games,
+                "sims_per_move": sims, "max_game_plies": plies, "games_adjudicated_at_ply_limit": int(res["adjudicated"]),
+                "cores": cores, "seconds": secs, "evaluator_only_rate": rate}
+
+    from cattus_amd import synth
+
+    dh = NetDesc(**hex_game(7), blocks=6, filters=64, vhc=16, phc=16)
+    out["selfplay"] = {
+        "hex7_6x64": path("hex7", seeded_blob(dh, 1), synth.random_hex_planes(4 * cores, 7, 1), 2, 100, {}),
+        # 64 simulations per move instead of the GPU leg's 800: one 800-sim move per game would already cost minutes here
+        "chess20x256": path("chess", blob, planes, 1, 64, SELFPLAY_SETTINGS),
+        "note": "C++ search (this repository) + oracle network through the C callback, one blocking search thread per CPU, batch_size 1; "
+                "games are cut after max_game_plies plies (bounded sample)",
+    }
+    return out
+
+
+# ------------------------------------------------------------------------------------------ plane pack roofline
 
 
 def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 20):
-    """HBM roofline of the plane-pack kernel (reference layout, f32 NCHW): chess planes for `leaves`
-    positions (1.25 GB of output, far beyond the 256 MiB Infinity Cache), timed with events on the
-    launch stream.  Algorithmic bytes per leaf = 18*8 in + 18*64*4 out = 4752."""
+    """HBM roofline of the stand-alone plane-pack kernel (reference layout, f32 NCHW; the drop-in for
+    planes_to_tensor, engine/src/net/mod.rs:121-156): chess planes for `leaves` positions (1.25 GB of
+    output, far beyond the 256 MiB Infinity Cache), timed with events on the launch stream.
+    Algorithmic bytes per leaf = 18*8 in + 18*64*4 out = 4752."""
     import ctypes as C
 
     planes = torch.randint(0, 2**62, (leaves, 18, 1), dtype=torch.int64, device=dev)
@@ -94,14 +159,15 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
         rc = ev_lib.cattus_hip_planes_to_tensor_device(planes.data_ptr(), leaves, 18, 1, 8, leaves, out.data_ptr(), C.c_void_p(stream.cuda_stream))
         assert rc == 0
 
-    for _ in range(3):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        launch()
-    e1.record(stream)
-    e1.synchronize()
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            launch()
+        e1.record(stream)
+        e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     nbytes = leaves * 4752
     # spot check against the definition
@@ -113,7 +179,7 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
             assert host[b, c].astype(int).tolist() == want
     achieved = nbytes / (us * 1e-6) / 1e9
     return {
-        "kernel": "planes_to_tensor_nchw_kernel",
+        "kernel": "planes_to_tensor_nchw64_kernel",
         "bound": "hbm",
         "achieved": achieved,
         "peak": 8000.0,
@@ -123,41 +189,91 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
         "avg_launch_us": us,
         "leaves_per_launch": leaves,
         "bytes_per_leaf": 4752,
+        "note": "stand-alone planes_to_tensor drop-in (cattus_hip_planes_to_tensor_device, reference layout); the forward pass "
+                "feeds its stem from pack_planes_nhwc_kernel instead (one launch of ~5 us at batch 256, launch-bound)",
     }
-
-
-def selfplay_leg(ev_blob, d, dtype: str, local_rank: int, rank: int, world: int, games: int, sims: int):
-    """End-to-end leg: real self-play (C++ search + evaluation cache + this GPU's evaluator) with the
-    reference's self-play settings (temperature 1.0 for 30 moves, Dirichlet 0.03/0.25:
-    training/config/chess_dev.yaml:52-68,83-88).  Every rank plays its own shard of the games."""
-    from cattus_amd import selfplay as sp
-    from cattus_amd.evaluator import HipEvaluator
-
-    threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
-    # keep the leg near a minute whatever CPU share this rank has: a host thread sustains roughly 25 k
-    # simulations/s of chess search, the GPU roughly 350 k evaluations/s, a game costs about 200 * sims leaves
-    capacity = min(350e3, threads * 25e3)
-    games = int(min(games, max(64, 60.0 * capacity / (200.0 * sims)))) // 2 * 2
-    slots = min(1024, games)  # >= 4 batches of leaves in flight keeps the batches full while other slots search
-    with HipEvaluator(ev_blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
-        cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
-                             temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25,
-                             first_game=rank, game_stride=world, seed=1)  # random streams are per global game index
-        t0 = time.perf_counter()
-        res = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, games, keep_records=False)
-        dt = time.perf_counter() - t0
-    return dict(seconds=dt, games=games, node_evals=res["node_evals"], batches=res["activation_count"], positions=res["positions"],
-                threads=threads, slots=slots, sims=sims, steady_rate=res["steady_node_evals"] / max(res["steady_seconds"], 1e-9),
-                steady_seconds=res["steady_seconds"])
 
 
 def measured_traffic(kernel: str):
     """HBM-side bytes per launch from the committed rocprofv3 PMC pass (profiles/), or None."""
-    try:
-        with open(ROOT / "profiles" / "r01_pmc_hbm_traffic.json") as f:
-            return json.load(f)[kernel]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        try:
+            with open(ROOT / "profiles" / name) as f:
+                return json.load(f)[kernel]["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+# ------------------------------------------------------------------------------------------ self-play legs
+
+
+def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, max_game_plies, keep_records, pool, torch, dev):
+    """Real self-play on this rank's shard of the games: C++ search + evaluation cache + this GPU's evaluator
+    through cattus_hip_eval (host buffers, PCIe included), the reference's self-play settings.  With `pool`
+    the records of all ranks are pooled by cattus_amd.dist.pool_records (all-gather) and the counters
+    all-reduced, inside the timed region."""
+    from cattus_amd import dist as cdist
+    from cattus_amd import selfplay as sp
+    from cattus_amd.evaluator import HipEvaluator
+
+    threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
+    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
+        cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
+                             first_game=rank, game_stride=world, seed=1, max_game_plies=max_game_plies,
+                             **SELFPLAY_SETTINGS)  # random streams are per global game index
+        t0 = time.perf_counter()
+        res = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, games, keep_records=keep_records)
+        play_s = time.perf_counter() - t0
+        pooled, pool_s = None, 0.0
+        if pool:
+            import torch.distributed as dist
+
+            t1 = time.perf_counter()
+            recs, _meta = cdist.pool_records(res["record_bytes"], res["record_meta"], device=dev)
+            tot = cdist.reduce_counters(res, device=dev)
+            torch.cuda.synchronize()
+            pool_s = time.perf_counter() - t1
+            pooled = dict(records=int(len(recs)), bytes=int(recs.size), draws=tot["draws"], p1=tot["player1_wins"], p2=tot["player2_wins"])
+            assert len(recs) == tot["positions"]
+    return dict(seconds=play_s + pool_s, play_seconds=play_s, pool_seconds=pool_s, games=games, node_evals=res["node_evals"],
+                batches=res["activation_count"], positions=res["positions"], threads=threads, slots=slots, sims=sims,
+                adjudicated=int(res["adjudicated"]), cache_hits=res["cache_hits"],
+                steady_rate=res["steady_node_evals"] / max(res["steady_seconds"], 1e-9), pooled=pooled)
+
+
+def reduce_leg(leg, torch, dev, world):
+    """Sum / max the per-rank figures of a self-play leg; returns the JSON object (identical on all ranks)."""
+    import torch.distributed as dist
+
+    t = torch.tensor([leg["seconds"], leg["games"], leg["node_evals"], leg["batches"], leg["positions"], leg["steady_rate"],
+                      leg["adjudicated"], leg["pool_seconds"], leg["cache_hits"]], dtype=torch.float64, device=dev)
+    tmax = t.clone()
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    secs = float(tmax[0].item())
+    games, evals, batches, plies = (float(t[i].item()) for i in (1, 2, 3, 4))
+    out = {
+        "node_evals_per_sec": evals / secs,
+        # while >= 3/4 of the concurrent-game slots still have a game to play, i.e. without the drain at the end of
+        # this fixed-size run when batches can no longer be filled (sum over GPUs)
+        "steady_node_evals_per_sec": float(t[5].item()),
+        "plies_per_sec": plies / secs,
+        "games": int(games),
+        "games_adjudicated_at_ply_limit": int(t[6].item()),
+        "sims_per_move": leg["sims"],
+        "plies_per_game": plies / max(1.0, games),
+        "batch_fill": evals / max(1.0, batches),
+        "cache_hit_rate": float(t[8].item()) / max(1.0, float(t[8].item()) + evals),
+        "concurrent_games_per_gpu": leg["slots"],
+        "host_threads_per_gpu": leg["threads"],
+        "seconds": secs,
+    }
+    return out
+
+
+# ------------------------------------------------------------------------------------------ main
 
 
 def main():
@@ -170,8 +286,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, choices=[1, 2], default=1,
                     help="2 = also time the K steps with two batches in flight (extra object; `value` stays single-stream)")
-    ap.add_argument("--selfplay-games", type=int, default=1024, help="games per GPU of the end-to-end self-play leg (0 = skip)")
-    ap.add_argument("--selfplay-sims", type=int, default=64)
+    ap.add_argument("--selfplay-seconds", type=float, default=40.0, help="time budget of the 800-sim self-play leg (0 = skip all self-play legs)")
+    ap.add_argument("--selfplay-sims", type=int, default=800, help="simulations per move of the end-to-end leg (BASELINE config 3: 800)")
+    ap.add_argument("--agreement-plies", type=int, default=4, help="searched plies per game of the bf16-vs-f32 search agreement leg (0 = skip)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32 (reference precision) object")
     args = ap.parse_args()
 
     import torch
@@ -182,112 +300,175 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the leaf evaluator has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    headline = args.workload == "chess20x256"
+    want_pg = world > 1 or (headline and args.selfplay_seconds > 0)  # config 4's leg pools records over RCCL, also on one rank
+    if want_pg:
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
 
     from cattus_amd.evaluator import HipEvaluator
 
     d, blob, planes = make_workload(args.workload)
     batch = len(planes)
     plane_words = planes.shape[2]
-    ev = HipEvaluator(blob, batch_size=batch, plane_words=plane_words, dtype=args.dtype, device=local_rank)
-
     dev = torch.device("cuda", local_rank)
     d_planes = torch.from_numpy(planes.view(np.int64)).to(dev)
-    d_policy = torch.empty((batch, d.moves), dtype=torch.float32, device=dev)
-    d_value = torch.empty((batch,), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream()
-
-    def step():
-        ev.eval_device(d_planes.data_ptr(), batch, d_policy.data_ptr(), d_value.data_ptr(), stream.cuda_stream)
+    stream = torch.cuda.Stream(device=dev)  # everything timed runs on this stream (not the legacy default stream)
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
 
-    # sanity: the timed kernels produced real numbers
-    assert bool(torch.isfinite(d_policy).all()) and bool(torch.isfinite(d_value).all())
+    def time_evaluator(dtype, steps, warmup, lanes=1):
+        """-> (seconds for `steps` steps, max over ranks; event-stamped tower launch µs; launches per step; outputs)"""
+        ev = HipEvaluator(blob, batch_size=batch, plane_words=plane_words, dtype=dtype, device=local_rank)
+        d_policy = torch.empty((batch, d.moves), dtype=torch.float32, device=dev)
+        d_value = torch.empty((batch,), dtype=torch.float32, device=dev)
 
-    # roofline of the dominant kernel (3x3 conv tower launch): event-stamped launch durations of the same
-    # forward, taken right behind the timed region so that the device is in the same state as for `value`
-    launch_us, launches = ev.time_tower(batch, 20) if rank == 0 else (0.0, 1)
+        def step():
+            ev.eval_device(d_planes.data_ptr(), batch, d_policy.data_ptr(), d_value.data_ptr(), stream.cuda_stream)
 
-    # ---- the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
-    # driver runs the evaluator: one batch's kernel tails overlap the other's heads.  Reported beside `value`.
-    def time_two_lanes():
-        side = torch.cuda.Stream(device=dev)
-        d_policy2, d_value2 = torch.empty_like(d_policy), torch.empty_like(d_value)
-        lanes = [(0, stream, d_policy, d_value), (1, side, d_policy2, d_value2)]
-
-        def step2(i):
-            lane, st, pol, val = lanes[i & 1]
-            ev.eval_device(d_planes.data_ptr(), batch, pol.data_ptr(), val.data_ptr(), st.cuda_stream, lane=lane)
-
-        for i in range(max(2, args.warmup // 2 * 2)):
-            step2(i)
+        for _ in range(warmup):
+            step()
         sync_all()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step2(i)
+        for _ in range(steps):
+            step()
         sync_all()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
-        return dt
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        # sanity: the timed kernels produced real numbers
+        assert bool(torch.isfinite(d_policy).all()) and bool(torch.isfinite(d_value).all())
+        # roofline of the dominant kernel (3x3 conv tower launch): event-stamped launch durations of the same
+        # forward, taken right behind the timed region so that the device is in the same state as for `value`
+        launch_us, launches = ev.time_tower(batch, 20) if rank == 0 else (0.0, 1)
+        elapsed2 = None
+        if lanes == 2:
+            # the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
+            # driver runs the evaluator: one batch's kernel tails overlap the other's heads
+            side = torch.cuda.Stream(device=dev)
+            d_policy2, d_value2 = torch.empty_like(d_policy), torch.empty_like(d_value)
+            both = [(0, stream, d_policy, d_value), (1, side, d_policy2, d_value2)]
 
-    elapsed2 = time_two_lanes() if args.lanes == 2 else None
+            def step2(i):
+                lane, st, pol, val = both[i & 1]
+                ev.eval_device(d_planes.data_ptr(), batch, pol.data_ptr(), val.data_ptr(), st.cuda_stream, lane=lane)
 
-    # ---- secondary measurement: end-to-end self-play games/hour (same network, real search on the host) ----
-    sp_out = None
-    if args.selfplay_games > 0 and args.workload == "chess20x256":
-        leg = selfplay_leg(blob, d, args.dtype, local_rank, rank, world, args.selfplay_games, args.selfplay_sims)
-        t = torch.tensor([leg["seconds"], leg["games"], leg["node_evals"], leg["batches"], leg["positions"], leg["steady_rate"]],
-                         dtype=torch.float64, device=dev)
-        tmax = t.clone()
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        secs = float(tmax[0].item())
-        sp_out = {
-            "games_per_hour": float(t[1].item()) * 3600.0 / secs,
-            "node_evals_per_sec": float(t[2].item()) / secs,
-            # while >= 3/4 of the concurrent-game slots still have a game to play, i.e. without the drain at
-            # the end of this fixed-size run when batches can no longer be filled (sum over GPUs)
-            "steady_node_evals_per_sec": float(t[5].item()),
-            "games": int(t[1].item()),
-            "sims_per_move": leg["sims"],
-            "plies_per_game": float(t[4].item()) / max(1.0, float(t[1].item())),
-            "batch_fill": float(t[2].item()) / max(1.0, float(t[3].item())),
-            "concurrent_games_per_gpu": leg["slots"],
-            "host_threads_per_gpu": leg["threads"],
-            "seconds": secs,
-            "settings": "temperature 1.0 for 30 moves then 0, Dirichlet noise 0.03/0.25, cache 1e6, batch 256",
+            for i in range(max(2, warmup // 2 * 2)):
+                step2(i)
+            sync_all()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step2(i)
+            sync_all()
+            elapsed2 = max_over_ranks(time.perf_counter() - t0)
+            assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
+        ev.close()
+        return elapsed, launch_us, launches, elapsed2, "conv3x3_mfma_v2_kernel"
+
+    def roofline(dtype, launch_us, launches, kernel):
+        flop_per_launch = d.conv_flops_per_position() * batch / launches
+        achieved = flop_per_launch / (launch_us * 1e-6) / 1e12
+        peak = MFMA_PEAK_TFLOPS[dtype]
+        return {
+            "kernel": kernel,
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": peak,
+            "unit": "TFLOP/s",
+            "frac": achieved / peak,
+            "traffic": measured_traffic(kernel) if headline and dtype == "bf16" else None,
+            "avg_launch_us": launch_us,
+            "launches_per_step": launches,
+            "flop_per_launch": flop_per_launch,
         }
+
+    elapsed, launch_us, launches, elapsed2, kname = time_evaluator(args.dtype, args.steps, args.warmup, args.lanes)
+    kname = kname or "conv3x3_mfma_v2_kernel"
+
+    f32_out = None
+    if args.dtype == "bf16" and not args.no_f32:
+        steps32 = max(5, args.steps // 10)
+        e32, us32, l32, _, k32 = time_evaluator("f32", steps32, max(2, args.warmup // 10))
+        if rank == 0:
+            f32_out = {
+                "value": world * batch * steps32 / e32,
+                "unit": "node-evals/s",
+                "ms_per_step": e32 / steps32 * 1e3,
+                "steps": steps32,
+                "dtype": "f32",
+                "note": "exact-f32 MFMA tower (v_mfma_f32_32x32x2_f32): the reference's precision, bit-identical to the CPU oracle",
+                "roofline": roofline("f32", us32, l32, k32 or "conv3x3_mfma_v2_kernel"),
+            }
+
+    # ---- bf16 vs f32 at SEARCH level (rank 0): 800-sim searches of the same positions with both towers
+    agreement = None
+    if headline and args.dtype == "bf16" and args.agreement_plies > 0 and rank == 0:
+        from cattus_amd import agreement as ag
+        from cattus_amd import selfplay as sp
+
+        games = 16
+        t0 = time.perf_counter()
+        with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="f32", device=local_rank, flush_us=100) as ev32:
+            cfg = sp.make_config(sim_num=800, temperature_policy=[(9999, 0.0)], cache_size=1000000)
+            opens = ag.random_openings("chess", games, 2, seed=7)
+            ta = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev32), opens, 2, args.agreement_plies)
+        lines = [op + [c for c, _ in t] for op, t in zip(opens, ta)]
+        with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="bf16", device=local_rank, flush_us=100) as ev16:
+            tb = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev16), lines, 2, args.agreement_plies)
+        agreement = ag.compare_traces(ta, tb)
+        agreement.update(games=games, sims_per_move=800, searched_plies_per_game=args.agreement_plies, seconds=time.perf_counter() - t0,
+                         note="f32 plays; bf16 searches the same positions (teacher-forced, trees carried over); greedy move choice, noise off. "
+                              "tests/test_search_parity_gpu.py runs 16 plies per game and bounds these numbers")
+
+    # ---- end-to-end self-play legs (all ranks; each plays its own shard of the games)
+    sp_out = sp_full = sp_c4 = None
+    if headline and args.selfplay_seconds > 0:
+        from cattus_amd import selfplay as sp
+
+        threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
+        # BASELINE config 3 as written: 800 sims/move, batch 256; enough concurrent games to fill two batches in
+        # flight; every game is cut after `plies` plies so that the leg fits its time budget (a whole 800-sim
+        # game of ~290 plies costs ~200 k evaluations, 512 of them ~5 minutes of GPU time)
+        capacity = min(330e3, threads * 12e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
+        plies = int(max(4, min(64, args.selfplay_seconds * capacity / (512 * 0.95 * args.selfplay_sims))))
+        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=512, slots=512, sims=args.selfplay_sims, max_game_plies=plies,
+                           keep_records=False, pool=False, torch=torch, dev=dev)
+        sp_out = reduce_leg(leg, torch, dev, world)
+        sp_out.update(max_game_plies=plies, settings=SELFPLAY_SETTINGS_TEXT,
+                      note="bounded sample: every game is adjudicated after max_game_plies plies; games_per_hour_estimate = plies_per_sec "
+                           "* 3600 / (plies per whole game measured in selfplay_full_games)")
+        # whole games, reduced simulation count: a measured games/hour
+        full_sims = 64
+        full_games = int(min(512, max(64, 20.0 * capacity / (200.0 * full_sims)))) // 2 * 2
+        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=full_games, slots=full_games, sims=full_sims, max_game_plies=0,
+                           keep_records=False, pool=False, torch=torch, dev=dev)
+        sp_full = reduce_leg(leg, torch, dev, world)
+        sp_full.update(games_per_hour=sp_full["games"] * 3600.0 / sp_full["seconds"], settings=SELFPLAY_SETTINGS_TEXT)
+        sp_out["games_per_hour_estimate"] = sp_out["plies_per_sec"] * 3600.0 / max(1.0, sp_full["plies_per_game"])
+        # BASELINE config 4's shape: 64 concurrent games per GPU (sequential search: at most 64 leaves per batch), records
+        # kept and pooled over RCCL (all-gather) with the counters all-reduced, all inside the timed region
+        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=64, slots=64, sims=args.selfplay_sims, max_game_plies=6,
+                           keep_records=True, pool=True, torch=torch, dev=dev)
+        sp_c4 = reduce_leg(leg, torch, dev, world)
+        sp_c4.update(max_game_plies=6, pool_seconds=leg["pool_seconds"], pooled=leg["pooled"], settings=SELFPLAY_SETTINGS_TEXT,
+                     note="64 games per GPU, records all-gathered and counters all-reduced through torch.distributed 'nccl' (= RCCL) inside "
+                          "the timed region; one leaf per tree in flight, so a batch holds at most 64 leaves")
 
     if rank == 0:
         value = world * batch * args.steps / elapsed
-        flop_per_launch = d.conv_flops_per_position() * batch / launches
-        achieved = flop_per_launch / (launch_us * 1e-6) / 1e12
-        peak = MFMA_PEAK_TFLOPS[args.dtype]
         out = {
             "metric": "MCTS node-evals/sec (chess 20x256 net, batch 256)",
             "value": value,
@@ -308,22 +489,14 @@ def main():
                 "flop_per_leaf": d.flops_per_position(),
             },
             "per_gpu_value": value / world,
-            "roofline": {
-                "kernel": "tower_persistent_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel",
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": achieved / peak,
-                "traffic": measured_traffic("tower_persistent_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel")
-                if args.workload == "chess20x256" and args.dtype == "bf16"
-                else None,
-                "avg_launch_us": launch_us,
-                "launches_per_step": launches,
-                "flop_per_launch": flop_per_launch,
-            },
+            "roofline": roofline(args.dtype, launch_us, launches, kname),
         }
-        if args.workload == "chess20x256":
+        out["whole_step_mfma_frac"] = d.flops_per_position() * batch / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype]
+        if f32_out is not None:
+            out["f32"] = f32_out
+        if agreement is not None:
+            out["bf16_search_agreement"] = agreement
+        if headline:
             from cattus_amd import evaluator as ev_mod
 
             out["roofline_plane_pack"] = pack_roofline(torch, ev_mod.load_library(), dev, stream)
@@ -334,13 +507,12 @@ def main():
                 "note": "same K steps alternating between the evaluator's two lanes on two streams",
             }
         if sp_out is not None:
-            out["selfplay"] = sp_out
+            out["selfplay"], out["selfplay_full_games"], out["selfplay_config4"] = sp_out, sp_full, sp_c4
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, planes)
         print(json.dumps(out), flush=True)
 
-    ev.close()
-    if world > 1:
+    if want_pg:
         dist.destroy_process_group()
 
 

@@ -782,6 +782,22 @@ CATTUS_API int cattus_hip_wait(cattus_eval* e, uint64_t ticket, float* policy, f
     }
 }
 
+CATTUS_API int cattus_hip_apply(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy, float* value) {
+    if (!e || !planes || !policy || !value) return fail(CATTUS_E_INVALID, "NULL argument");
+    const size_t words = (size_t)e->d.planes * e->cfg.plane_words;
+    std::vector<uint64_t> tickets(n);
+    int rc = CATTUS_OK;
+    uint32_t submitted = 0;
+    for (; submitted < n; submitted++)
+        if ((rc = cattus_hip_submit(e, planes + submitted * words, &tickets[submitted]))) break;
+    // every submitted ticket is collected, also after a failure, so that no batch stays behind
+    for (uint32_t i = 0; i < submitted; i++) {
+        const int wrc = cattus_hip_wait(e, tickets[i], policy + (size_t)i * e->d.moves, value + i);
+        if (wrc && !rc) rc = wrc;
+    }
+    return rc;
+}
+
 CATTUS_API int cattus_hip_flush(cattus_eval* e) {
     if (!e) return fail(CATTUS_E_INVALID, "NULL argument");
     {

@@ -50,8 +50,9 @@ SelfPlayConfig to_config(const cattus_sp_config* c) {
     cfg.game_stride = std::max(1u, c->game_stride);
     cfg.host_alloc = c->host_alloc;
     cfg.host_free = c->host_free;
-    cfg.eval_threads = c->eval_threads ? std::min(c->eval_threads, 8u) : 2;
+    cfg.eval_threads = c->eval_threads ? std::min(c->eval_threads, 256u) : 2;
     cfg.mcts.leaves_in_flight = std::max(1u, std::min(c->leaves_in_flight, 16u));
+    cfg.max_game_plies = c->max_game_plies;
     return cfg;
 }
 
@@ -259,6 +260,7 @@ SP_API int cattus_sp_run(int game, const cattus_sp_config* c, cattus_net_eval_fn
         s.run_duration = m.run_duration_ema, s.search_duration = m.search_duration_ema;
         s.seconds = r.seconds;
         s.steady_seconds = r.steady_seconds, s.steady_node_evals = r.steady_node_evals;
+        s.adjudicated = r.adjudicated;
         res->record_bytes = Serializer<G>::RECORD_BYTES;
         if (!keep_records) res->records.clear();
         std::sort(res->records.begin(), res->records.end(), [](const Record& a, const Record& b) {

@@ -306,6 +306,7 @@ struct SelfPlayConfig {
     uint64_t seed = 1;
     // this process plays global game indices first_game + k*game_stride, k = 0..games_num-1
     uint32_t first_game = 0, game_stride = 1;
+    uint32_t max_game_plies = 0;  // > 0 (not in the reference): adjudicate a draw after this many plies
     // optional allocator for the batch buffers handed to the network callback (page-locked memory
     // from cattus_hip_host_alloc lets the evaluator DMA straight into them)
     void* (*host_alloc)(size_t) = nullptr;
@@ -320,6 +321,7 @@ struct SelfPlayResult {
     // when the last games finish and batches can no longer be filled)
     double steady_seconds = 0;
     uint64_t steady_node_evals = 0;
+    uint64_t adjudicated = 0;  // games cut at max_game_plies
 };
 
 template <typename G>
@@ -632,9 +634,11 @@ class SelfPlayRunner {
                     break;
                 }
                 case Slot::NEXT_MOVE: {
-                    const Status st = s.game.status();
+                    Status st = s.game.status();
+                    bool cut = false;
+                    if (!st.finished && cfg_.max_game_plies && s.game.history.size() > cfg_.max_game_plies) st = Status::draw(), cut = true;
                     if (st.finished) {
-                        finish_game(s, st.winner, d1, d2, records, res, out_mu);
+                        finish_game(s, st.winner, d1, d2, records, res, out_mu, cut);
                         s.state = Slot::IDLE;
                         break;
                     }
@@ -705,7 +709,7 @@ class SelfPlayRunner {
 
     // write_data_entry for every stored position + win counters (self_play.rs:219-241,248-275)
     void finish_game(Slot& s, int8_t winner, const std::string& d1, const std::string& d2, std::vector<Record>* records,
-                     SelfPlayResult& res, std::mutex& out_mu) {
+                     SelfPlayResult& res, std::mutex& out_mu, bool adjudicated = false) {
         std::vector<Record> recs;
         for (size_t pos_idx = 0; pos_idx < s.pairs.size(); pos_idx++) {
             const Position& pos = s.pairs[pos_idx].first;
@@ -738,6 +742,7 @@ class SelfPlayRunner {
             if (records) records->push_back(std::move(r));
         }
         res.positions += s.pairs.size();
+        if (adjudicated) res.adjudicated++;
         if (winner == 0) res.d++;
         else {
             int8_t w = winner;

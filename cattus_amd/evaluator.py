@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "cattus_hip_submit",
     "cattus_hip_wait",
     "cattus_hip_flush",
+    "cattus_hip_apply",
     "cattus_hip_host_alloc",
     "cattus_hip_host_free",
     "cattus_hip_stats",
@@ -109,6 +110,7 @@ def load_library():
     L.cattus_hip_submit.argtypes = [vp, u64p, C.POINTER(C.c_uint64)]
     L.cattus_hip_wait.argtypes = [vp, C.c_uint64, f32p, f32p]
     L.cattus_hip_flush.argtypes = [vp]
+    L.cattus_hip_apply.argtypes = [vp, u64p, C.c_uint32, f32p, f32p]
     L.cattus_hip_host_alloc.argtypes = [C.c_size_t]
     L.cattus_hip_host_alloc.restype = vp
     L.cattus_hip_host_free.argtypes = [vp]

@@ -82,6 +82,7 @@ class SpConfig(C.Structure):
         ("legal_net2", C.c_void_p),
         ("eval_threads", C.c_uint32),
         ("leaves_in_flight", C.c_uint32),
+        ("max_game_plies", C.c_uint32),
     ]
 
 
@@ -101,6 +102,7 @@ class SpSummary(C.Structure):
         ("seconds", C.c_double),
         ("steady_seconds", C.c_double),
         ("steady_node_evals", C.c_uint64),
+        ("adjudicated", C.c_uint64),
     ]
 
 
@@ -188,6 +190,7 @@ def make_config(
     game_stride: int = 1,
     eval_threads: int = 0,
     leaves_in_flight: int = 1,
+    max_game_plies: int = 0,
 ) -> SpConfig:
     c = SpConfig()
     c.struct_size = C.sizeof(SpConfig)
@@ -201,6 +204,7 @@ def make_config(
     c.cache_size, c.batch_size, c.threads = cache_size, batch_size, max(1, min(threads, available_cpus()))
     c.concurrent_games, c.seed, c.first_game, c.game_stride = concurrent_games, seed, first_game, game_stride
     c.eval_threads = eval_threads  # 0 = the driver's default (2 batches in flight)
+    c.max_game_plies = max_game_plies  # > 0: adjudicate a draw after that many plies (bounded samples; not in the reference)
     c.leaves_in_flight = leaves_in_flight  # > 1: several leaves per tree at the network (virtual loss), not in the reference
     return c
 
@@ -252,6 +256,18 @@ class Net:
         net.host_alloc = C.cast(evaluator._lib.cattus_hip_host_alloc, C.c_void_p).value
         net.host_free = C.cast(evaluator._lib.cattus_hip_host_free, C.c_void_p).value
         return net
+
+    @staticmethod
+    def hip_batched(evaluator) -> "Net":
+        """cattus_hip_apply: a blocking call per search thread, batched across threads by the evaluator's
+        leaf server -- the reference's threading model (one thread per game meeting in Batcher::apply)."""
+        fn = C.cast(evaluator._lib.cattus_hip_apply, C.c_void_p).value
+        return Net(fn, evaluator._h.value, keepalive=evaluator)
+
+    @staticmethod
+    def raw(fn_addr: int, ctx: int, keepalive=None) -> "Net":
+        """Any C function with the cattus_net_eval_fn signature (e.g. the CPU oracle's callback, tests / bench baseline)."""
+        return Net(fn_addr, ctx, keepalive=keepalive)
 
     @staticmethod
     def python(fn) -> "Net":

@@ -113,6 +113,11 @@ int cattus_hip_lane_stream(cattus_eval* e, uint32_t lane, void** stream);
 int cattus_hip_submit(cattus_eval* e, const uint64_t* planes_one, uint64_t* ticket);
 int cattus_hip_wait(cattus_eval* e, uint64_t ticket, float* policy, float* value);
 int cattus_hip_flush(cattus_eval* e);
+/* Batcher::apply as the reference's worker threads call it (engine/src/util/batch.rs:49-177,
+ * net/mod.rs:94-98): a blocking call with the signature of cattus_hip_eval that goes through the leaf
+ * server, i.e. the n leaves (n = 1 from a search thread) share batches with whatever the other calling
+ * threads submit meanwhile; a batch runs when max_batch leaves are queued or flush_us have passed. */
+int cattus_hip_apply(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy, float* value);
 
 /* Page-locked host memory.  cattus_hip_eval transfers directly from / into buffers allocated here
  * (no staging copy); any other host memory works too, through the evaluator's own staging buffers. */

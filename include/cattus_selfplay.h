@@ -67,6 +67,10 @@ typedef struct cattus_sp_config {
      * to k unexpanded leaves at the network together, each holding a virtual loss on its path; fills
      * batches from few concurrent games at the price of a search that differs from the sequential one */
     uint32_t leaves_in_flight;
+    /* 0: games end by the rules only (the reference).  k > 0 (not in the reference): a game still running
+     * after k plies is adjudicated a draw there and its records are written as such; for bounded
+     * benchmark samples of long games (summary field `adjudicated` counts them) */
+    uint32_t max_game_plies;
 } cattus_sp_config;
 
 typedef struct cattus_sp_summary {
@@ -81,6 +85,7 @@ typedef struct cattus_sp_summary {
      * i.e. without the drain at the end when batches can no longer be filled */
     double steady_seconds;
     uint64_t steady_node_evals;
+    uint64_t adjudicated;       /* games cut at max_game_plies (counted among the draws) */
 } cattus_sp_summary;
 
 typedef struct cattus_sp_result cattus_sp_result;

@@ -42,6 +42,8 @@ def lib():
         L.oracle_softmax_legal.restype = None
         L.oracle_softmax_legal_det.argtypes = [f32p, C.POINTER(C.c_uint16), C.c_uint32, f32p]
         L.oracle_softmax_legal_det.restype = None
+        L.oracle_net_eval_cb.argtypes = [C.c_void_p, u64p, C.c_uint32, f32p, f32p]
+        L.oracle_net_eval_cb.restype = C.c_int
         L.oracle_tanhf.argtypes = [C.c_float]
         L.oracle_tanhf.restype = C.c_float
         _LIB = L
@@ -95,6 +97,17 @@ class OracleNet:
         assert rc == 0
         return policy, value
 
+    def callback(self, plane_words: int, threads: int = 1):
+        """(function address, context address, keepalive) of oracle_net_eval_cb: the oracle behind the
+        host library's network-callback signature (cattus_net_eval_fn), no Python in the loop."""
+
+        class Ctx(C.Structure):
+            _fields_ = [("net", C.c_void_p), ("w64", C.c_uint32), ("threads", C.c_int32)]
+
+        ctx = Ctx(self._h, plane_words, threads)
+        fn = C.cast(lib().oracle_net_eval_cb, C.c_void_p).value
+        return fn, C.addressof(ctx), (ctx, self)
+
     def forward_debug(self, planes_one: np.ndarray):
         d = self.desc
         planes_one = np.ascontiguousarray(planes_one, dtype=np.uint64).reshape(d.planes, -1)
@@ -145,4 +158,13 @@ def tanhf(x: float) -> float:
 
 
 def default_threads() -> int:
-    return len(os.sched_getaffinity(0))
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask
+    (a container's mask can list every core of the host while its quota grants a few)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n

@@ -270,11 +270,25 @@ static const int KPERM[8] = {0, 4, 1, 5, 2, 6, 3, 7};
  * the canonical chain: one fmaf per (chunk, tap, k) in that order, zero taps included; a vector
  * fma lane rounds exactly like fmaf. */
 #define ACC_MAX (MAX_S * (MAX_S + 2) + 16)
+/* Zeroed per-thread scratch for the padded input planes.  It is kept between calls: a calloc/free of
+ * ~150 KB per layer goes through mmap/munmap, whose page faults serialise the threads of one process
+ * (16 OpenMP threads then run no faster than one). */
+static float *conv_scratch(size_t n) {
+    static __thread float *buf = NULL;
+    static __thread size_t cap = 0;
+    if (n > cap) {
+        free(buf);
+        buf = (float *)malloc(n * sizeof(float));
+        cap = buf ? n : 0;
+    }
+    if (buf) memset(buf, 0, n * sizeof(float));
+    return buf;
+}
 #define CONV3X3_BODY(SWEEP)                                                                              \
     const uint32_t hw = S * S, P = S + 2, cin = L->cin, cout = L->cout;                                   \
     const uint32_t span = (S * P + 15) & ~15u;                                                            \
     const uint32_t plane = P * P + P + 32; /* slack: the last tap's sweep stays in bounds */              \
-    float *xpad = (float *)calloc((size_t)cin * plane, sizeof(float));                                    \
+    float *xpad = conv_scratch((size_t)cin * plane);                                                      \
     for (uint32_t c = 0; c < cin; c++)                                                                    \
         for (uint32_t h = 0; h < S; h++)                                                                  \
             for (uint32_t w = 0; w < S; w++)                                                              \
@@ -303,8 +317,7 @@ static const int KPERM[8] = {0, 4, 1, 5, 2, 6, 3, 7};
                 if (res) y = y + res[co * hw + i];                                                        \
                 out[co * hw + i] = y > 0.0f ? y : 0.0f;                                                   \
             }                                                                                             \
-    }                                                                                                     \
-    free(xpad);
+    }
 
 #define SWEEP_SCALAR(acc, xp, wv, span) \
     for (uint32_t i = 0; i < (span); i++) (acc)[i] = __builtin_fmaf((wv), (xp)[i], (acc)[i])
@@ -448,6 +461,20 @@ ORACLE_API int oracle_net_forward(const oracle_net *net, const uint64_t *planes,
     }
     (void)threads;
     return rc;
+}
+
+/* The same behind the network-callback signature of the host library (cattus_net_eval_fn,
+ * include/cattus_selfplay.h), so that the C++ search can run on the CPU oracle with no Python in the
+ * loop: bench.py's cpu_baseline leg and the parity tests.  ctx -> {net, plane words, threads}. */
+typedef struct oracle_cb_ctx {
+    const oracle_net *net;
+    uint32_t w64;
+    int32_t threads;
+} oracle_cb_ctx;
+ORACLE_API int oracle_net_eval_cb(void *ctx, const uint64_t *planes, uint32_t n, float *policy, float *value) {
+    const oracle_cb_ctx *c = (const oracle_cb_ctx *)ctx;
+    if (!c) return -1;
+    return oracle_net_forward(c->net, planes, c->w64, n, policy, value, c->threads);
 }
 
 /* Single position with intermediate activations, NCHW [F][hw] each. */
