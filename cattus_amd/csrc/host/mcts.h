@@ -14,6 +14,15 @@
 //   * Iterator::max_by keeps the LAST maximal element -> ties go to the earliest-inserted child;
 //   * remove_all_but_subtree re-adds children in edges() order -> sibling order reverses on every
 //     tree reuse (mcts/mod.rs:303-333).
+//
+// Child nodes are materialised lazily.  The reference's create_children makes one node (a moved position)
+// per legal move at once (mcts/mod.rs:246-262); at 800 simulations per move only ~1 in 30 of them is ever
+// visited.  Here an expansion creates the EDGES only (move, prior, n, w -- everything selection and the
+// result read); the child's node, i.e. its position, is made when a selection first walks the edge.
+// Nothing observable depends on when a node is made: selection, backup and the visit counts read edges,
+// repetition detection reads the positions of the selected path (materialised by the selection), and the
+// tree-reuse lookup compares positions in the reference's breadth-first order, computing those of
+// unmaterialised children on the fly.  Trees are ~20x smaller and an expansion costs one make-move, not 30.
 #pragma once
 #include <cassert>
 #include <cmath>
@@ -109,7 +118,7 @@ class MctsPlayer {
             const int node = find_node_with_position(position, 3);
             if (node >= 0) {
                 remove_all_but_subtree((uint32_t)node);
-            } else {
+            } else {  // not in the tree, or a child nobody visited: either way the new tree is the bare root
                 nodes_.clear();
                 edges_.clear();
                 has_root_ = false;
@@ -137,7 +146,7 @@ class MctsPlayer {
         while (sims_done_ + inflight_n_ < params_.sim_num && inflight_n_ < K) {
             InFlight& f = inflight_[inflight_n_];
             select(f.path);
-            const uint32_t leaf = f.path.empty() ? root_ : edges_[f.path.back()].target;
+            const uint32_t leaf = f.path.empty() ? root_ : edges_[f.path.back()].target;  // made by select()
             if (nodes_[leaf].pending) break;  // selection ran into a leaf already waiting: evaluate what we have
             const bool repetition = detect_repetition(f.path);
             const Status st = nodes_[leaf].status();
@@ -254,7 +263,8 @@ class MctsPlayer {
             return Status{(bool)st_finished, st_winner};
         }
     };
-    struct Edge {  // MctsEdge (mcts/mod.rs:32-45) + endpoints
+    static constexpr uint32_t NO_NODE = 0xffffffffu;
+    struct Edge {  // MctsEdge (mcts/mod.rs:32-45) + endpoints (target NO_NODE until a selection walks the edge)
         Move m;
         float init_score;
         uint32_t n;
@@ -273,7 +283,7 @@ class MctsPlayer {
         return exploit + explore;
     }
 
-    void select(std::vector<uint32_t>& path) const {  // mcts/mod.rs:199-231
+    void select(std::vector<uint32_t>& path) {  // mcts/mod.rs:199-231
         path.clear();
         uint32_t node_id = root_;
         for (;;) {
@@ -293,8 +303,19 @@ class MctsPlayer {
                 }
             }
             path.push_back(best);
-            node_id = edges_[best].target;
+            node_id = target_node(best);
         }
+    }
+
+    // the node an edge leads to, made on first use (see the note on lazy nodes at the top of the file)
+    uint32_t target_node(uint32_t e) {
+        if (edges_[e].target == NO_NODE) {
+            const uint32_t child = (uint32_t)nodes_.size();
+            Position np = nodes_[edges_[e].source].pos.moved(edges_[e].m);
+            nodes_.push_back(Node(np, 0, 0));
+            edges_[e].target = child;
+        }
+        return edges_[e].target;
     }
 
     // mcts/mod.rs:133-154: count equal positions over game history + search path; the first position
@@ -341,14 +362,9 @@ class MctsPlayer {
     }
 
     void create_children(uint32_t parent, const std::vector<std::pair<Move, float>>& per_move) {  // mcts/mod.rs:246-262
-        const Position parent_pos = nodes_[parent].pos;
         nodes_[parent].first = (uint32_t)edges_.size();
         nodes_[parent].count = (uint32_t)per_move.size();
-        for (auto& mp : per_move) {
-            const uint32_t child = (uint32_t)nodes_.size();
-            nodes_.push_back(Node(parent_pos.moved(mp.first), 0, 0));
-            edges_.push_back(Edge{mp.first, mp.second, 0, 0.0f, parent, child});
-        }
+        for (auto& mp : per_move) edges_.push_back(Edge{mp.first, mp.second, 0, 0.0f, parent, NO_NODE});
     }
 
     void backpropagate(const std::vector<uint32_t>& path, float score) {  // mcts/mod.rs:270-281
@@ -359,14 +375,27 @@ class MctsPlayer {
         }
     }
 
-    int find_node_with_position(const Position& position, uint32_t depth_limit) const {  // mcts/mod.rs:283-301
-        std::vector<uint32_t> layer{root_}, next;
+    // mcts/mod.rs:283-301: breadth-first over `depth_limit` layers, children in edges() order, first equal
+    // position wins.  Returns the node, FOUND_UNMADE if the first match is a child whose node was never
+    // made (it has no subtree: the caller starts from a single root), or -1.
+    static constexpr int FOUND_UNMADE = -2;
+    int find_node_with_position(const Position& position, uint32_t depth_limit) const {
+        struct Ref {
+            uint32_t node;  // NO_NODE: the unmade target of `edge`
+            uint32_t edge;
+        };
+        std::vector<Ref> layer{Ref{root_, 0}}, next;
         for (uint32_t d = 0; d < depth_limit; d++) {
             next.clear();
-            for (uint32_t node : layer) {
-                if (nodes_[node].pos == position) return (int)node;
-                const Node& nd = nodes_[node];
-                for (uint32_t i = nd.count; i-- > 0;) next.push_back(edges_[nd.first + i].target);
+            for (const Ref& r : layer) {
+                if (r.node == NO_NODE) {
+                    const Edge& e = edges_[r.edge];
+                    if (nodes_[e.source].pos.moved(e.m) == position) return FOUND_UNMADE;
+                    continue;  // no node, no children
+                }
+                if (nodes_[r.node].pos == position) return (int)r.node;
+                const Node& nd = nodes_[r.node];
+                for (uint32_t i = nd.count; i-- > 0;) next.push_back(Ref{edges_[nd.first + i].target, nd.first + i});
             }
             layer.swap(next);
         }
@@ -375,10 +404,15 @@ class MctsPlayer {
 
     void remove_all_but_subtree(uint32_t sub_root) {  // mcts/mod.rs:303-333
         if (root_ == sub_root) return;
-        std::vector<Node> nn;
-        std::vector<Edge> ne;
+        // the copy goes into a second pair of vectors kept by the player: no allocation once they have grown
+        std::vector<Node>& nn = nodes2_;
+        std::vector<Edge>& ne = edges2_;
+        nn.clear();
+        ne.clear();
         nn.push_back(nodes_[sub_root]);
-        std::vector<std::pair<uint32_t, uint32_t>> stack{{sub_root, 0}};
+        std::vector<std::pair<uint32_t, uint32_t>>& stack = copy_stack_;
+        stack.clear();
+        stack.emplace_back(sub_root, 0u);
         while (!stack.empty()) {
             const auto [po, pn] = stack.back();
             stack.pop_back();
@@ -387,6 +421,10 @@ class MctsPlayer {
             nn[pn].count = old.count;
             for (uint32_t i = old.count; i-- > 0;) {  // edges() order; re-added in that order
                 const Edge& e = edges_[old.first + i];
+                if (e.target == NO_NODE) {
+                    ne.push_back(Edge{e.m, e.init_score, e.n, e.w, pn, NO_NODE});
+                    continue;
+                }
                 const uint32_t cn = (uint32_t)nn.size();
                 nn.push_back(nodes_[e.target]);
                 ne.push_back(Edge{e.m, e.init_score, e.n, e.w, pn, cn});
@@ -420,8 +458,9 @@ class MctsPlayer {
 
     MctsParams params_;
     Rng rng_;
-    std::vector<Node> nodes_;
-    std::vector<Edge> edges_;
+    std::vector<Node> nodes_, nodes2_;
+    std::vector<Edge> edges_, edges2_;
+    std::vector<std::pair<uint32_t, uint32_t>> copy_stack_;
     uint32_t root_ = 0;
     bool has_root_ = false;
 
