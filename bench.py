@@ -439,12 +439,12 @@ def main():
         from cattus_amd import selfplay as sp
 
         threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
-        # BASELINE config 3 as written: 800 sims/move, batch 256; enough concurrent games to fill two batches in
-        # flight; every game is cut after `plies` plies so that the leg fits its time budget (a whole 800-sim
-        # game of ~290 plies costs ~200 k evaluations, 512 of them ~5 minutes of GPU time)
-        capacity = min(330e3, threads * 12e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
-        plies = int(max(4, min(64, args.selfplay_seconds * capacity / (512 * 0.95 * args.selfplay_sims))))
-        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=512, slots=512, sims=args.selfplay_sims, max_game_plies=plies,
+        # BASELINE config 3 as written: 800 sims/move, batch 256; 1024 concurrent games (two batches in flight
+        # and two more ready to go); every game is cut after `plies` plies so that the leg fits its time budget (a whole
+        # 800-sim game of ~290 plies costs ~170 k evaluations, 1024 of them ~9 minutes of GPU time)
+        capacity = min(330e3, threads * 60e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
+        plies = int(max(4, min(64, args.selfplay_seconds * capacity / (1024 * 0.75 * args.selfplay_sims))))
+        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=1024, slots=1024, sims=args.selfplay_sims, max_game_plies=plies,
                            keep_records=False, pool=False, torch=torch, dev=dev)
         sp_out = reduce_leg(leg, torch, dev, world)
         sp_out.update(max_game_plies=plies, settings=SELFPLAY_SETTINGS_TEXT,
@@ -452,7 +452,7 @@ def main():
                            "* 3600 / (plies per whole game measured in selfplay_full_games)")
         # whole games, reduced simulation count: a measured games/hour
         full_sims = 64
-        full_games = int(min(512, max(64, 20.0 * capacity / (200.0 * full_sims)))) // 2 * 2
+        full_games = int(min(1024, max(64, 25.0 * capacity / (190.0 * full_sims)))) // 2 * 2
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=full_games, slots=full_games, sims=full_sims, max_game_plies=0,
                            keep_records=False, pool=False, torch=torch, dev=dev)
         sp_full = reduce_leg(leg, torch, dev, world)

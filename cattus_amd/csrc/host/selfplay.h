@@ -47,7 +47,11 @@ struct NetHandle {
 };
 
 struct Metrics {
-    std::atomic<uint64_t> cache_hits{0}, cache_misses{0}, activation_count{0}, node_evals{0};
+    // every simulation bumps one of the first two from some search thread: keep them off each other's cache line
+    alignas(64) std::atomic<uint64_t> cache_hits{0};
+    alignas(64) std::atomic<uint64_t> cache_misses{0};
+    alignas(64) std::atomic<uint64_t> activation_count{0};
+    std::atomic<uint64_t> node_evals{0};
     double run_duration_ema = 0.0, search_duration_ema = 0.0;  // RunningAverage eps 0.99 (util/metric.rs)
     std::mutex mu;
     void set_run(double s) {
@@ -63,8 +67,10 @@ struct Metrics {
 // ---- evaluation cache (mcts/cache.rs): key = position flipped to Player1, FIFO eviction -----------
 // One FIFO of max_size positions, as the reference's single deque (cache.rs:62-66), so that evictions --
 // and with them the cache.hits / cache.misses counters of the summary -- are those of a reference run with
-// the same evaluation order.  The reference guards map and deque with one RwLock; here the map is split
-// into shards (a probe locks 1/64 of it) and only the eviction order is global.
+// the same evaluation order.  The reference guards map and deque with one RwLock; every leaf of every
+// search thread goes through here (hundreds of thousands per second), so the map is split into shards
+// (a probe locks 1/64 of it) and the eviction order is kept by a queue whose lock is held for a push and
+// a pop only -- a sleeping lock around the whole insert serialised the search threads into a convoy.
 template <typename G>
 class EvalCache {
    public:
@@ -84,10 +90,6 @@ class EvalCache {
     // returns false if the position was already present (the reference then returns the cached value)
     bool insert(const typename G::Position& pos, const Evaluation<G>& ev, Evaluation<G>* existing) {
         const uint64_t h = pos.hash();
-        // The FIFO lock is held across the whole insert, like the reference's write lock: "evict while
-        // len >= max_size, then push" (cache.rs:62-70) stays atomic.  Shard locks nest inside it, never
-        // the other way round.
-        std::lock_guard<std::mutex> fl(fifo_mu_);
         {
             Shard& s = shards_[h % SHARDS];
             std::lock_guard<std::mutex> lk(s.mu);
@@ -97,43 +99,54 @@ class EvalCache {
                     if (existing) *existing = it->second.second;
                     return false;
                 }
-        }
-        while (fifo_.size() >= max_size_) {
-            const typename G::Position& old = fifo_.front();
-            const uint64_t oh = old.hash();
-            Shard& os = shards_[oh % SHARDS];
-            {
-                std::lock_guard<std::mutex> lk(os.mu);
-                auto r = os.map.equal_range(oh);
-                for (auto it = r.first; it != r.second; ++it)
-                    if (it->second.first == old) {
-                        os.map.erase(it);
-                        break;
-                    }
-            }
-            fifo_.pop_front();
-        }
-        {
-            Shard& s = shards_[h % SHARDS];
-            std::lock_guard<std::mutex> lk(s.mu);
             s.map.emplace(h, std::make_pair(pos, ev));
         }
-        fifo_.push_back(pos);
+        // "remove the oldest while len >= max_size, then insert" (cache.rs:62-70): after either order of the two
+        // steps the cache holds the newest max_size positions
+        typename G::Position victim;
+        bool evict = false;
+        {
+            SpinGuard g(fifo_lock_);
+            fifo_.push_back(pos);
+            if (fifo_.size() > max_size_) {
+                victim = fifo_.front();
+                fifo_.pop_front();
+                evict = true;
+            }
+        }
+        if (evict) {
+            const uint64_t oh = victim.hash();
+            Shard& os = shards_[oh % SHARDS];
+            std::lock_guard<std::mutex> lk(os.mu);
+            auto r = os.map.equal_range(oh);
+            for (auto it = r.first; it != r.second; ++it)
+                if (it->second.first == victim) {
+                    os.map.erase(it);
+                    break;
+                }
+        }
         return true;
     }
     size_t size() {
-        std::lock_guard<std::mutex> fl(fifo_mu_);
+        SpinGuard g(fifo_lock_);
         return fifo_.size();
     }
 
    private:
+    struct SpinGuard {
+        std::atomic_flag& f;
+        explicit SpinGuard(std::atomic_flag& fl) : f(fl) {
+            while (f.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause();
+        }
+        ~SpinGuard() { f.clear(std::memory_order_release); }
+    };
     static constexpr size_t SHARDS = 64;
-    struct Shard {
+    struct alignas(64) Shard {
         std::mutex mu;
         std::unordered_multimap<uint64_t, std::pair<typename G::Position, Evaluation<G>>> map;
     };
     Shard shards_[SHARDS];
-    std::mutex fifo_mu_;
+    alignas(64) std::atomic_flag fifo_lock_ = ATOMIC_FLAG_INIT;
     std::deque<typename G::Position> fifo_;
     size_t max_size_;
 };
