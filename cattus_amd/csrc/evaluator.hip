@@ -220,6 +220,8 @@ struct cattus_eval {
     bool wait_spin = true;  // host wait for a batch: spinning hipStreamSynchronize, or a blocking event
     Act act = Act::F32;
     uint32_t hw = 0, bpad = 0, cpad0 = 0;
+    uint32_t slots = 64;  // pixel slots per board of the tuned tower (kernels.h: tower_slots)
+    uint32_t fpad = 0;    // filters as laid out on the device: rounded up to 64 on the tuned path (zero channels)
     int device = 0;
 
     ConvLayer stem;
@@ -269,35 +271,39 @@ size_t blob_floats(const cattus_net_desc& d) {
     return n;
 }
 
-// Upload one folded 3x3 layer in the layout of the selected tower.
-int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, uint32_t cin) {
+// Upload one folded 3x3 layer in the layout of the selected tower.  On the tuned path output channels are
+// padded to `cout_pad` and input channels to the device layout of the producing layer (`cin_pad`, a multiple of
+// one 128-byte row) with zero weights and zero bias: a padded channel computes relu(0) = 0, and as an input it
+// adds fmaf(0, x, acc) = acc terms only, so the f32 chains of the real channels are bit for bit unchanged.
+int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, uint32_t cin, uint32_t cout_pad, uint32_t cin_pad) {
     int rc;
-    if ((rc = L.b.upload(f.b.data(), cout * sizeof(float)))) return rc;
     if (!e->tuned) {
         L.cin = cin;
+        if ((rc = L.b.upload(f.b.data(), cout * sizeof(float)))) return rc;
         return L.w.upload(f.w.data(), f.w.size() * sizeof(float));
     }
-    const uint32_t kc = (uint32_t)act_kc(e->act);
-    const uint32_t cpad = (cin + kc - 1) / kc * kc;
-    L.cin = cpad;
+    std::vector<float> b(cout_pad, 0.0f);
+    memcpy(b.data(), f.b.data(), cout * sizeof(float));
+    if ((rc = L.b.upload(b.data(), b.size() * sizeof(float)))) return rc;
+    L.cin = cin_pad;
     if (e->act == Act::BF16) {
-        std::vector<uint16_t> w((size_t)9 * cout * cpad, 0);
+        std::vector<uint16_t> w((size_t)9 * cout_pad * cin_pad, 0);
         for (uint32_t t = 0; t < 9; t++)
             for (uint32_t co = 0; co < cout; co++)
                 for (uint32_t ci = 0; ci < cin; ci++)
-                    w[((size_t)t * cout + co) * cpad + ci] = f32_to_bf16(f.w[((size_t)t * cout + co) * cin + ci]);
+                    w[((size_t)t * cout_pad + co) * cin_pad + ci] = f32_to_bf16(f.w[((size_t)t * cout + co) * cin + ci]);
         return L.w.upload(w.data(), w.size() * 2);
     }
-    std::vector<float> w((size_t)9 * cout * cpad, 0.0f);
+    std::vector<float> w((size_t)9 * cout_pad * cin_pad, 0.0f);
     for (uint32_t t = 0; t < 9; t++)
         for (uint32_t co = 0; co < cout; co++)
-            memcpy(&w[((size_t)t * cout + co) * cpad], &f.w[((size_t)t * cout + co) * cin], cin * sizeof(float));
+            memcpy(&w[((size_t)t * cout_pad + co) * cin_pad], &f.w[((size_t)t * cout + co) * cin], cin * sizeof(float));
     return L.w.upload(w.data(), w.size() * 4);
 }
 
 int build(cattus_eval* e, const float* p) {
     const cattus_net_desc& d = e->d;
-    const uint32_t F = d.filters, hw = e->hw;
+    const uint32_t F = d.filters, hw = e->hw, FP = e->fpad;
     auto take = [&](size_t n) {
         const float* r = p;
         p += n;
@@ -307,7 +313,8 @@ int build(cattus_eval* e, const float* p) {
     {
         const float* w = take((size_t)F * d.planes * 9);
         const float *g = take(F), *be = take(F), *mu = take(F), *var = take(F);
-        if ((rc = upload_conv(e, e->stem, fold_conv(w, F, d.planes, 9, g, be, mu, var), F, d.planes))) return rc;
+        const uint32_t kc = e->tuned ? (uint32_t)act_kc(e->act) : 1;
+        if ((rc = upload_conv(e, e->stem, fold_conv(w, F, d.planes, 9, g, be, mu, var), F, d.planes, FP, (d.planes + kc - 1) / kc * kc))) return rc;
         e->cpad0 = e->stem.cin;
     }
     for (uint32_t i = 0; i < d.blocks; i++) {
@@ -315,10 +322,10 @@ int build(cattus_eval* e, const float* p) {
         e->c2.emplace_back(new ConvLayer);
         const float* w1 = take((size_t)F * F * 9);
         const float *mu1 = take(F), *var1 = take(F);
-        if ((rc = upload_conv(e, *e->c1.back(), fold_conv(w1, F, F, 9, nullptr, nullptr, mu1, var1), F, F))) return rc;
+        if ((rc = upload_conv(e, *e->c1.back(), fold_conv(w1, F, F, 9, nullptr, nullptr, mu1, var1), F, F, FP, FP))) return rc;
         const float* w2 = take((size_t)F * F * 9);
         const float *g2 = take(F), *be2 = take(F), *mu2 = take(F), *var2 = take(F);
-        if ((rc = upload_conv(e, *e->c2.back(), fold_conv(w2, F, F, 9, g2, be2, mu2, var2), F, F))) return rc;
+        if ((rc = upload_conv(e, *e->c2.back(), fold_conv(w2, F, F, 9, g2, be2, mu2, var2), F, F, FP, FP))) return rc;
     }
     // heads: value rows first, then policy rows, in one [vhc+phc][F] 1x1 conv
     std::vector<float> hw_w((size_t)(d.vhc + d.phc) * F), hw_b(d.vhc + d.phc);
@@ -346,12 +353,12 @@ int build(cattus_eval* e, const float* p) {
     if ((rc = e->bp.upload(pfc_b, d.moves * 4))) return rc;
     if (e->tuned) {
         // K-contiguous matrices, K padded to 16 with zeros (zero terms do not change an fmaf chain)
-        const uint32_t ocn = d.vhc + d.phc, F_ = F;
+        const uint32_t ocn = d.vhc + d.phc;
         e->kvp = (kv + 15) / 16 * 16;
         e->kpp = (kp + 15) / 16 * 16;
         const uint32_t m32 = (d.moves + 31) / 32 * 32;
-        std::vector<float> cw((size_t)32 * F_, 0.0f), w1((size_t)FC_HIDDEN * e->kvp, 0.0f), wp((size_t)m32 * e->kpp, 0.0f);
-        memcpy(cw.data(), hw_w.data(), (size_t)ocn * F_ * 4);
+        std::vector<float> cw((size_t)32 * FP, 0.0f), w1((size_t)FC_HIDDEN * e->kvp, 0.0f), wp((size_t)m32 * e->kpp, 0.0f);
+        for (uint32_t oc = 0; oc < ocn; oc++) memcpy(&cw[(size_t)oc * FP], &hw_w[(size_t)oc * F], (size_t)F * 4);
         for (uint32_t j = 0; j < FC_HIDDEN; j++) memcpy(&w1[(size_t)j * e->kvp], &fc1_w[(size_t)j * kv], kv * 4);
         for (uint32_t m = 0; m < d.moves; m++) memcpy(&wp[(size_t)m * e->kpp], &pfc_w[(size_t)m * kp], kp * 4);
         auto upload_t = [&](DevBuf& buf, const std::vector<float>& v) -> int {
@@ -378,15 +385,16 @@ int build(cattus_eval* e, const float* p) {
     // activations
     const size_t bp_ = e->bpad, B = e->cfg.max_batch;
     const size_t esz = e->tuned ? (size_t)act_bytes(e->act) : 4;
-    const size_t slots = e->tuned ? SLOTS : hw;
+    const size_t slots = e->tuned ? e->slots : hw;
+    const size_t FA = e->tuned ? FP : F;  // channels of the tower buffers
     for (Lane& L : e->lanes) {
         HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventBlockingSync | hipEventDisableTiming));
         if ((rc = L.d_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
         if ((rc = L.x0.alloc(bp_ * slots * e->cpad0 * esz))) return rc;
-        if ((rc = L.a.alloc(bp_ * slots * F * esz))) return rc;
-        if ((rc = L.t.alloc(bp_ * slots * F * esz))) return rc;
-        if ((rc = L.y.alloc(bp_ * slots * F * esz))) return rc;
+        if ((rc = L.a.alloc(bp_ * slots * FA * esz))) return rc;
+        if ((rc = L.t.alloc(bp_ * slots * FA * esz))) return rc;
+        if ((rc = L.y.alloc(bp_ * slots * FA * esz))) return rc;
         if ((rc = L.hv.alloc(bp_ * (e->kvp + e->kpp) * esz))) return rc;
         HIP_TRY(hipMemset(L.hv.p, 0, bp_ * (e->kvp + e->kpp) * esz));  // pad columns must read as zero
         if ((rc = L.h1.alloc(bp_ * FC_HIDDEN * 4))) return rc;
@@ -419,24 +427,26 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
     void *a = L.a.p, *t = L.t.p, *y = L.y.p;
     uint32_t nb = n;
     if (e->tuned) {
-        nb = (n + BOARDS_PER_WG - 1) / BOARDS_PER_WG * BOARDS_PER_WG;
+        const uint32_t bpw = ROWS_PER_WG / e->slots;  // boards per workgroup of the conv kernel
+        const uint32_t FP = e->fpad;
+        nb = (n + bpw - 1) / bpw * bpw;
         launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
         {
             // every launch is told which weights come next, so that its idle loader waves can pull them into L2
-            const size_t wbytes = (size_t)9 * F * F * act_bytes(e->act);
+            const size_t wbytes = (size_t)9 * FP * FP * act_bytes(e->act);
             auto next_w = [&](uint32_t block, int which) -> const void* {  // which: 0 = conv1, 1 = conv2 of `block`
                 if (block >= d.blocks) return nullptr;
                 return which == 0 ? e->c1[block]->w.p : e->c2[block]->w.p;
             };
             hipEvent_t s0 = ev(false), s1 = ev(true);
-            launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, F, S, st, s0, s1,
+            launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
                                 next_w(0, 0), wbytes);
             for (uint32_t i = 0; i < d.blocks; i++) {
                 s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, F, F, S, st, s0, s1,
+                launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1,
                                     next_w(i, 1), wbytes);
                 s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, F, F, S, st, s0, s1,
+                launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1,
                                     next_w(i + 1, 0), wbytes);
                 std::swap(a, y);
             }
@@ -464,7 +474,8 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         hd.wp = e->wpt.p, hd.bp = e->bp.as<float>(), hd.policy = d_policy;
         hd.hw = hw, hd.vhc = d.vhc, hd.phc = d.phc, hd.kvp = e->kvp, hd.kpp = e->kpp, hd.M = d.moves;
         hd.w2 = e->w2.as<float>(), hd.b2 = e->b2.as<float>(), hd.value = d_value;
-        launch_heads_mfma(e->act, a, n, F, hd, st);
+        hd.slots = e->slots;
+        launch_heads_mfma(e->act, a, n, e->fpad, hd, st);
     } else {
         TowerView tv;
         tv.x = a, tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;
@@ -657,7 +668,6 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
         return fail(CATTUS_E_DEVICE, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(herr));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(CATTUS_E_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
-    if (const char* impl = getenv("CATTUS_CONV_IMPL")) set_conv_impl(atoi(impl) == 1 ? 1 : 2);
     const char* wait_mode = getenv("CATTUS_HIP_WAIT");
     if (const char* pf = getenv("CATTUS_PREFETCH")) set_conv_prefetch(atoi(pf) != 0);
 
@@ -669,11 +679,18 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->device = cfg->device;
     e->wait_spin = !(wait_mode && strcmp(wait_mode, "block") == 0);
     e->hw = d.board * d.board;
-    e->tuned = d.board <= 8 && d.filters % COUT_PER_WG == 0 && d.vhc + d.phc <= 32;
+    // The MFMA tower covers every board up to 11x11 and any filter count (channels are padded to 64 with zeros);
+    // the two 1x1 head convs share one 32-row MFMA tile.  Wider heads take the generic f32 path (one thread
+    // per output, same arithmetic order), which otherwise serves as a checker only (CATTUS_FORCE_GENERIC=1).
+    const char* force_generic = getenv("CATTUS_FORCE_GENERIC");
+    e->tuned = d.vhc + d.phc <= 32 && !(force_generic && force_generic[0] == '1');
     e->act = cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16 : Act::F32;
     if (!e->tuned && e->act == Act::BF16)
-        return fail(CATTUS_E_UNSUPPORTED, "bf16 tower needs filters %% 64 == 0 and board <= 8 (got %u filters, board %u)", d.filters, d.board);
-    e->bpad = (cfg->max_batch + BOARDS_PER_WG - 1) / BOARDS_PER_WG * BOARDS_PER_WG;
+        return fail(CATTUS_E_UNSUPPORTED, "bf16 needs the MFMA tower: value + policy head channels <= 32 (got %u + %u)", d.vhc, d.phc);
+    e->slots = tower_slots(d.board);
+    e->fpad = e->tuned ? (d.filters + COUT_PER_WG - 1) / COUT_PER_WG * COUT_PER_WG : d.filters;
+    const uint32_t bpw = e->tuned ? ROWS_PER_WG / e->slots : 1;
+    e->bpad = (cfg->max_batch + bpw - 1) / bpw * bpw;
     int rc = build(e.get(), reinterpret_cast<const float*>((const char*)weights + HEADER_BYTES));
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());

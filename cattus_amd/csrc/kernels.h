@@ -5,8 +5,9 @@
 
 namespace cattus {
 
-constexpr int SLOTS = 64;        // pixel slots per board in the tower layout (board edge <= 8)
-constexpr int BOARDS_PER_WG = 4; // boards per workgroup of the tower conv kernel
+// Tower layout: a board owns 64 pixel slots (board edge <= 8) or 128 (edge 9..11); rows = board * slots + slot.
+inline uint32_t tower_slots(uint32_t S) { return S <= 8 ? 64u : 128u; }
+constexpr int ROWS_PER_WG = 256; // tower rows per workgroup of the conv kernel: 4 boards of 64 slots, 2 of 128
 constexpr int COUT_PER_WG = 64;  // output channels per workgroup of the tower conv kernel
 
 // Activation element of the tuned tower: 2-byte bf16 or 4-byte f32.
@@ -17,7 +18,7 @@ inline int act_bytes(Act a) { return a == Act::BF16 ? 2 : 4; }
 inline int act_kc(Act a) { return 128 / act_bytes(a); }
 
 // ---- K0: bitboard planes -> tensors -------------------------------------------------------
-// NHWC tower input [bpad][64][cpad] (rows >= n, slots >= S*S and channels >= C are zero).
+// NHWC tower input [bpad][slots][cpad] (rows >= n, slots >= S*S and channels >= C are zero).
 void launch_pack_planes_nhwc(Act act, const uint64_t* planes, uint32_t n, uint32_t bpad, uint32_t C,
                              uint32_t w64, uint32_t S, uint32_t cpad, void* out, hipStream_t st);
 // Reference layout: f32 NCHW [batch][C][S*S], rows >= n zero (engine/src/net/mod.rs:121-156).
@@ -25,8 +26,8 @@ void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C
                                   uint32_t batch, float* out, hipStream_t st);
 
 // ---- K1/K2: 3x3 conv + folded BN (+ residual) + ReLU, MFMA, NHWC -------------------------
-// in [bpad][64][cin], w [9][cout][cin], bias [cout] f32, res/out [bpad][64][cout].
-// Requires bpad % 4 == 0, cin % kc == 0, cout % 64 == 0, S <= 8.
+// in [bpad][slots][cin], w [9][cout][cin], bias [cout] f32, res/out [bpad][slots][cout], slots = tower_slots(S).
+// Requires bpad * slots % 256 == 0, cin % kc == 0, cout % 64 == 0, S <= 11.
 // ev_start / ev_stop (optional): events stamped with the kernel's own begin / end time.
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
@@ -34,9 +35,6 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                          size_t w_next_bytes = 0);
 // w_next (optional): weight tensor of the layer that runs next; the launch's idle loader waves pull it into L2.
 void set_conv_prefetch(bool on);
-
-// Selects the tower kernel variant (1 or 2); for A/B measurements only.
-void set_conv_impl(int v);
 
 // Generic f32 NCHW direct conv for shapes the MFMA kernel does not cover (any S <= 11, any C).
 // in [b][cin][hw], w [9][cout][cin], out [b][cout][hw]; same summation order as the MFMA f32 kernel.
@@ -62,6 +60,7 @@ struct HeadsMfma {
     const float *w2, *b2;  // value FC2 [128], [1]
     float* value;          // [nb], tanh applied
     uint32_t hw, vhc, phc, kvp, kpp, M;
+    uint32_t slots;  // pixel slots per board of the tower (tower_slots)
 };
 void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, const HeadsMfma& hd, hipStream_t st);
 

@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 template <typename T>
 __global__ void __launch_bounds__(256) pack_planes_nhwc_kernel(const uint64_t* __restrict__ planes, uint32_t n,
                                                                uint32_t C, uint32_t w64, uint32_t hw, uint32_t cpad,
-                                                               T* __restrict__ out) {
+                                                               uint32_t slots, T* __restrict__ out) {
     constexpr uint32_t VEC = 16 / sizeof(T);
     __shared__ uint64_t pl[128];
     const uint32_t b = blockIdx.x;
@@ -43,8 +43,8 @@ __global__ void __launch_bounds__(256) pack_planes_nhwc_kernel(const uint64_t* _
     for (uint32_t i = threadIdx.x; i < words; i += 256) pl[i] = b < n ? planes[(size_t)b * words + i] : 0ull;
     __syncthreads();
     const uint32_t groups = cpad / VEC;
-    T* ob = out + (size_t)b * SLOTS * cpad;
-    for (uint32_t v = threadIdx.x; v < SLOTS * groups; v += 256) {
+    T* ob = out + (size_t)b * slots * cpad;
+    for (uint32_t v = threadIdx.x; v < slots * groups; v += 256) {
         const uint32_t q = v / groups, c0 = (v % groups) * VEC;
         T vals[VEC];
 #pragma unroll
@@ -87,12 +87,13 @@ __global__ void __launch_bounds__(256) planes_to_tensor_nchw_kernel(const uint64
 
 void launch_pack_planes_nhwc(Act act, const uint64_t* planes, uint32_t n, uint32_t bpad, uint32_t C, uint32_t w64,
                              uint32_t S, uint32_t cpad, void* out, hipStream_t st) {
+    const uint32_t slots = tower_slots(S);
     if (act == Act::BF16)
         hipLaunchKernelGGL(pack_planes_nhwc_kernel<__bf16>, dim3(bpad), dim3(256), 0, st, planes, n, C, w64, S * S, cpad,
-                           (__bf16*)out);
+                           slots, (__bf16*)out);
     else
         hipLaunchKernelGGL(pack_planes_nhwc_kernel<float>, dim3(bpad), dim3(256), 0, st, planes, n, C, w64, S * S, cpad,
-                           (float*)out);
+                           slots, (float*)out);
 }
 
 // 8x8 boards: one plane = 64 floats = 256 B.  A thread turns one nibble of the plane word into 4 floats
@@ -150,27 +151,15 @@ void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C
 //
 // out^T[cout][pixel] = sum_{chunk, tap, k} W[tap][cout][chunk*KC + k] * in[pixel + tap][chunk*KC + k]
 //
-// Workgroup = 4 waves = 4 boards x 64 output channels; wave w owns board w: a 64(cout) x 64(pixel)
-// tile = 2x2 MFMA 32x32 accumulators.  Weights are the MFMA A operand (row = cout), activations
-// the B operand (col = pixel), so each lane ends up with 4 consecutive couts of one pixel -> 8/16-byte
-// NHWC stores.
+// Weights are the MFMA A operand (row = cout), activations the B operand (col = pixel), so each lane ends
+// up with 4 consecutive couts of one pixel.  K is walked as (chunk of one 128-byte row = KC channels) x
+// (9 taps); the activation chunk of a workgroup's 256 pixel rows is loaded once per chunk and re-read by
+// all 9 taps with shifted pixel rows (out-of-board lanes read a zero row), so activations cross L2->LDS
+// once, not nine times.  LDS rows are XOR-swizzled at 16-byte granularity (chunk ^ ((row>>1)&7)) on the
+// global SOURCE side and on the ds_read side; the LDS-DMA destination stays lane-linear.
 //
-// K is walked as (chunk of one 128-byte row = KC channels) x (9 taps).  Per step one 8 KiB weight
-// slab [64 cout][128 B] is consumed; the 32 KiB activation chunk [4 boards][64 px][128 B] is loaded
-// once per chunk and re-read by all 9 taps with shifted pixel rows (out-of-board lanes read a zero
-// row), so activations cross L2->LDS once, not nine times.
-//
-// Staging is LDS-DMA (global_load_lds_dwordx4): every step each wave issues exactly three 1 KiB
-// pieces (one activation piece of the NEXT chunk or a dummy, two weight pieces of step t+2 or
-// dummies), so a constant s_waitcnt vmcnt(3) retires everything step t needs.  LDS rows are
-// XOR-swizzled at 16-byte granularity (chunk ^ ((row>>1)&7)) on the global SOURCE side and on the
-// ds_read side; the DMA destination stays lane-linear.
-
-constexpr int LDS_ZERO = 0;                       // 128 B of zeros (padding rows)
-constexpr int LDS_ACT = 128;                      // 2 x 32 KiB
-constexpr int LDS_W = LDS_ACT + 2 * 32768;        // 3 x 8 KiB
-constexpr int LDS_SCRATCH = LDS_W + 3 * 8192;     // 4 x 1 KiB dummy DMA targets
-constexpr int LDS_TOTAL = LDS_SCRATCH + 4 * 1024; // 94336 B
+// Tower layout: a board owns 64 pixel slots (board edge <= 8) or 128 (edge 9..11); a workgroup always
+// covers 256 consecutive tower rows = 4 boards of 64 slots or 2 boards of 128.
 
 template <typename T>
 struct Mfma;
@@ -218,191 +207,9 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
 }
-template <typename T, bool HAS_RES>
-__global__ void __launch_bounds__(256, 1)
-    conv3x3_mfma_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-                        const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S) {
-    constexpr int KC = 128 / (int)sizeof(T);
-    typedef typename Mfma<T>::frag frag;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int r = lane & 31, h = lane >> 5;
-
-    // XCD-aware block order: blocks with equal blockIdx % 8 share an L2, so give each such group a
-    // contiguous range of board groups (all cout blocks of a board group stay on one XCD).
-    const int nblk = gridDim.x, ncb = cout / COUT_PER_WG;
-    int logical = blockIdx.x;
-    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int cout0 = (logical % ncb) * COUT_PER_WG;
-    const int b0 = (logical / ncb) * BOARDS_PER_WG;
-
-    if (tid < 8) reinterpret_cast<f32x4*>(smem + LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
-
-    const int nch = cin / KC;
-    const int T_total = nch * 9;
-    const size_t row_bytes = (size_t)cin * sizeof(T);
-
-    // ---- staging helpers (lane i of a DMA piece fills LDS row i>>3, 16-byte slot i&7) ----
-    const int prow = lane >> 3, pslot = lane & 7;
-    auto stage_w = [&](int t, int slot) {
-        const int ch = t / 9, tap = t - ch * 9;
-        const char* wb = reinterpret_cast<const char*>(w) + ((size_t)(tap * cout + cout0)) * row_bytes + (size_t)ch * 128;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int row0 = wave * 16 + j * 8;
-            const int row = row0 + prow;
-            const int c = pslot ^ ((row >> 1) & 7);
-            glds16(wb + (size_t)row * row_bytes + c * 16, smem + LDS_W + slot * 8192 + row0 * 128);
-        }
-    };
-    auto stage_a = [&](int ch, int piece, int buf) {
-        const int id = piece * 4 + wave;  // 0..31, 8 rows each
-        const int row = id * 8 + prow;    // 0..255 = board*64 + pixel slot
-        const int c = pslot ^ ((row >> 1) & 7);
-        const char* src = reinterpret_cast<const char*>(in) + ((size_t)b0 * SLOTS + row) * row_bytes + (size_t)ch * 128 + c * 16;
-        glds16(src, smem + LDS_ACT + buf * 32768 + id * 1024);
-    };
-    auto stage_dummy = [&]() {
-        glds16(reinterpret_cast<const char*>(w) + lane * 16, smem + LDS_SCRATCH + wave * 1024);
-    };
-
-    // ---- per-lane geometry ----
-    int ph[2], pw[2];
-    bool pvalid[2];
-#pragma unroll
-    for (int pb = 0; pb < 2; pb++) {
-        const int p = pb * 32 + r;
-        ph[pb] = p / S;
-        pw[pb] = p - ph[pb] * S;
-        pvalid[pb] = p < S * S;
-    }
-    int arow[2], ax0[2];  // weight fragment rows: LDS byte offset of the row, swizzle term
-#pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
-        const int row = cb * 32 + r;
-        arow[cb] = row * 128;
-        ax0[cb] = (h ^ ((row >> 1) & 7)) << 4;
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-
-    // ---- prologue: activation chunk 0, weight slabs 0 and 1 ----
-#pragma unroll
-    for (int pc = 0; pc < 8; pc++) stage_a(0, pc, 0);
-    stage_w(0, 0);
-    stage_w(1, 1);
-
-    int ch = 0, tap = 0;
-    for (int t = 0; t < T_total; t++) {
-        // Everything step t reads was issued before step t-1's loads: allow only those 3 in flight.
-        if (t == 0)
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-
-        // Issue: next chunk's activation piece (taps 0..7) and the weight slab of step t+2.
-        if (tap < 8 && ch + 1 < nch)
-            stage_a(ch + 1, tap, (ch + 1) & 1);
-        else
-            stage_dummy();
-        if (t + 2 < T_total) {
-            stage_w(t + 2, (t + 2) % 3);
-        } else {
-            stage_dummy();
-            stage_dummy();
-        }
-
-        // ---- compute step t ----
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int abase = LDS_ACT + (ch & 1) * 32768 + wave * 8192;
-        const int wbase = LDS_W + (t % 3) * 8192;
-        int brow[2], bx0[2];
-#pragma unroll
-        for (int pb = 0; pb < 2; pb++) {
-            const int hh = ph[pb] + dy, ww = pw[pb] + dx;
-            const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
-            const int q = hh * S + ww;
-            brow[pb] = ok ? abase + q * 128 : LDS_ZERO;
-            bx0[pb] = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            frag a[2], b[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; cb++)
-                a[cb] = *reinterpret_cast<const frag*>(smem + wbase + arow[cb] + (ax0[cb] ^ (ks << 5)));
-#pragma unroll
-            for (int pb = 0; pb < 2; pb++)
-                b[pb] = *reinterpret_cast<const frag*>(smem + brow[pb] + (bx0[pb] ^ (ks << 5)));
-#pragma unroll
-            for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-                for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(a[cb], b[pb], acc[cb][pb]);
-        }
-
-        if (++tap == 9) {
-            tap = 0;
-            ch++;
-        }
-    }
-    // Dummy DMA pieces may still be in flight: they must land before this workgroup's LDS is reused.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // ---- epilogue: + bias (+ residual), ReLU, NHWC store; lane holds 4 consecutive couts per group ----
-    const size_t board = (size_t)(b0 + wave);
-#pragma unroll
-    for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-        for (int pb = 0; pb < 2; pb++) {
-            const int p = pb * 32 + r;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = cout0 + cb * 32 + g * 8 + h * 4;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
-                const size_t off = (board * SLOTS + p) * (size_t)cout + co;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
-                if (HAS_RES) {
-                    T rv[4];
-                    if (sizeof(T) == 2)
-                        *reinterpret_cast<uint64_t*>(rv) = *reinterpret_cast<const uint64_t*>(res + off);
-                    else
-                        *reinterpret_cast<f32x4*>(rv) = *reinterpret_cast<const f32x4*>(res + off);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = v[i] + (float)rv[i];
-                }
-                T ov[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    float y = v[i] > 0.0f ? v[i] : 0.0f;
-                    if (!pvalid[pb]) y = 0.0f;
-                    ov[i] = (T)y;
-                }
-                if (sizeof(T) == 2)
-                    *reinterpret_cast<uint64_t*>(out + off) = *reinterpret_cast<uint64_t*>(ov);
-                else
-                    *reinterpret_cast<f32x4*>(out + off) = *reinterpret_cast<f32x4*>(ov);
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------
-// K1 v2: same tiling and arithmetic, specialised wave roles
-// ------------------------------------------------------------------------------------------
-//
-// 8 waves per workgroup: waves 0-3 are MFMA consumers (one board each, as above), waves 4-7 are
-// loaders that do nothing but LDS-DMA.  One barrier per (chunk, kernel row): a step covers the
+// Workgroup = 8 waves = 256 tower rows x 64 output channels.  Waves 0-3 are MFMA consumers: wave w owns
+// rows w*64 .. w*64+63 (a whole 64-slot board, or half of a 128-slot board) = a 64(cout) x 64(pixel)
+// tile = 2x2 MFMA 32x32 accumulators; waves 4-7 are loaders that do nothing but LDS-DMA.  One barrier per (chunk, kernel row): a step covers the
 // three taps dx = -1,0,+1 of one dy, i.e. 48 MFMAs (bf16) per consumer wave between barriers, and
 // a 24 KiB weight slab [3 taps][64 cout][128 B].  Loaders run two steps ahead (3-slab ring) and
 // fetch the next activation chunk during the first two steps of the current one.  Consumers issue
@@ -429,7 +236,8 @@ constexpr int NLOAD = CATTUS_NLOAD;
 constexpr int WPL = 24 / NLOAD;  // weight pieces per loader wave and step
 constexpr int APL = 16 / NLOAD;  // activation pieces per loader wave and half-chunk
 
-template <typename T, bool HAS_RES>
+// BIG: 128 pixel slots per board (two consumer waves per board).
+template <typename T, bool HAS_RES, bool BIG>
 __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                            const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S,
@@ -450,7 +258,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     int logical = blockIdx.x;
     if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int cout0 = (logical % ncb) * COUT_PER_WG;
-    const int b0 = (logical / ncb) * BOARDS_PER_WG;
+    const int row0 = (logical / ncb) * ROWS_PER_WG;  // first tower row (board * slots + pixel slot) of this workgroup
 
     if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
@@ -484,7 +292,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 dst_a[g][i] = id * 1024;
             }
         const char* wbase0 = reinterpret_cast<const char*>(w) + (size_t)cout0 * row_bytes;
-        const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)b0 * SLOTS * row_bytes;
+        const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
         auto issue_w = [&](int t) {  // weight slab of step t -> ring slot t % 3
             const int ch = t / 3, g = t - ch * 3;
             const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)ch * 128;
@@ -578,11 +386,14 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     __builtin_amdgcn_s_setprio(1);  // MFMA waves win issue arbitration against the loader wave on their SIMD
 #endif
     const int r = lane & 31, h = lane >> 5;
+    // pixel slot of this lane's two output columns within its board, and the LDS offset of the board's rows
+    const int pslot0 = BIG ? (wave & 1) * 64 : 0;
+    const int board_lds = BIG ? (wave >> 1) * 16384 : wave * 8192;
     int ph[2], pw[2];
     bool pvalid[2];
 #pragma unroll
     for (int pb = 0; pb < 2; pb++) {
-        const int p = pb * 32 + r;
+        const int p = pslot0 + pb * 32 + r;
         ph[pb] = p / S;
         pw[pb] = p - ph[pb] * S;
         pvalid[pb] = p < S * S;
@@ -617,7 +428,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     if (RES_EARLY) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const size_t off = ((size_t)(b0 + wave) * SLOTS + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
+            const size_t off = ((size_t)row0 + wave * 64 + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
             *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
         }
     }
@@ -628,7 +439,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     constexpr int AHEAD = 2, RING = 3;
     int opaque = 0;
     for (int ch = 0; ch < nch; ch++) {
-        const int abase = V2_LDS_ACT + (ch & 1) * 32768 + wave * 8192;
+        const int abase = V2_LDS_ACT + (ch & 1) * 32768 + board_lds;
 #pragma unroll
         for (int g = 0; g < 3; g++) {
             // all fragment reads of the previous step have returned before the loaders may reuse its slab
@@ -689,14 +500,19 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     // (XOR-swizzled 16-byte slots), then every lane owns 8 consecutive couts of one pixel: one
     // 16/32-byte residual load and one 16/32-byte store per lane and pixel row, whole 128-byte lines.
     STAMP(2);
+    if (BIG) {
+        // the staging region below holds pixel rows the OTHER wave of this board may still be reading as
+        // neighbours in its last step: meet first (the loader waves have left; a barrier counts live waves)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     {
-        const size_t board = (size_t)(b0 + wave);
+        const size_t wrow0 = (size_t)row0 + wave * 64;  // first tower row of this wave's tile
         const int tile0 = V2_LDS_ACT + wave * 8192;  // px 0..31; px 32..63 live 32768 bytes further
         // skip-connection rows in the final (pixel row, 8 couts) layout, requested before the transpose
         if (HAS_RES && !RES_EARLY) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const size_t off = (board * SLOTS + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
+                const size_t off = (wrow0 + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
                 if (sizeof(T) == 2) {
                     *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
                 } else {
@@ -726,12 +542,12 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (rr & 7)) << 4));
             const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (rr & 7)) << 4));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const size_t off = (board * SLOTS + px) * (size_t)cout + cout0 + cg * 8;
+            const size_t off = (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
             if (HAS_RES) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = v[j] + (float)resv[i][j];
             }
-            const bool valid = px < S * S;
+            const bool valid = pslot0 + px < S * S;
             T ov[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -767,8 +583,6 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 }
 #endif
 
-int g_conv_impl = 2;  // 1 = single-role kernel above, 2 = loader/consumer kernel
-void set_conv_impl(int v) { g_conv_impl = v; }
 bool g_conv_prefetch = true;  // loader waves pull the next layer's weights into L2 (A/B switch: CATTUS_PREFETCH=0)
 void set_conv_prefetch(bool on) { g_conv_prefetch = on; }
 
@@ -777,46 +591,32 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                          hipEvent_t ev_stop, const void* w_next, size_t w_next_bytes) {
     const char* wn = g_conv_prefetch ? (const char*)w_next : nullptr;
     const int wn_lines = (int)(w_next_bytes / 128);
-    const dim3 grid((bpad / BOARDS_PER_WG) * (cout / COUT_PER_WG)), block(256);
-#define CATTUS_LAUNCH_CONV2(T, R)                                                                         \
+    const uint32_t slots = tower_slots(S);
+    const dim3 grid((bpad * slots / ROWS_PER_WG) * (cout / COUT_PER_WG));
+#define CATTUS_LAUNCH_CONV2(T, R, BIG)                                                                    \
     do {                                                                                                  \
         static std::atomic<uint64_t> attr_set{0};                                                         \
         if (first_use_on_device(attr_set)) {                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R>),      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R, BIG>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
         }                                                                                                 \
-        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
                               (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, wn, wn_lines); \
     } while (0)
-    if (g_conv_impl == 2) {
-        if (act == Act::BF16) {
-            if (res) CATTUS_LAUNCH_CONV2(__bf16, true);
-            else CATTUS_LAUNCH_CONV2(__bf16, false);
-        } else {
-            if (res) CATTUS_LAUNCH_CONV2(float, true);
-            else CATTUS_LAUNCH_CONV2(float, false);
-        }
-        return;
-    }
-#undef CATTUS_LAUNCH_CONV2
-#define CATTUS_LAUNCH_CONV(T, R)                                                                          \
-    do {                                                                                                  \
-        static std::atomic<uint64_t> attr_set{0};                                                         \
-        if (first_use_on_device(attr_set)) {                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<T, R>),         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);             \
-        }                                                                                                 \
-        hipExtLaunchKernelGGL((conv3x3_mfma_kernel<T, R>), grid, block, LDS_TOTAL, st, ev_start, ev_stop, 0, (const T*)in, \
-                              (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S);    \
+#define CATTUS_LAUNCH_CONV2_T(T)                             \
+    do {                                                     \
+        if (slots == 128) {                                  \
+            if (res) CATTUS_LAUNCH_CONV2(T, true, true);     \
+            else CATTUS_LAUNCH_CONV2(T, false, true);        \
+        } else {                                             \
+            if (res) CATTUS_LAUNCH_CONV2(T, true, false);    \
+            else CATTUS_LAUNCH_CONV2(T, false, false);       \
+        }                                                    \
     } while (0)
-    if (act == Act::BF16) {
-        if (res) CATTUS_LAUNCH_CONV(__bf16, true);
-        else CATTUS_LAUNCH_CONV(__bf16, false);
-    } else {
-        if (res) CATTUS_LAUNCH_CONV(float, true);
-        else CATTUS_LAUNCH_CONV(float, false);
-    }
-#undef CATTUS_LAUNCH_CONV
+    if (act == Act::BF16) CATTUS_LAUNCH_CONV2_T(__bf16);
+    else CATTUS_LAUNCH_CONV2_T(float);
+#undef CATTUS_LAUNCH_CONV2_T
+#undef CATTUS_LAUNCH_CONV2
 }
 
 // ------------------------------------------------------------------------------------------
@@ -877,7 +677,7 @@ enum { EPI_HEADCONV = 0, EPI_FC1 = 1, EPI_POLICY = 2 };
 struct HeadEpi {
     const float* bias;
     void* out;
-    uint32_t hw, vhc, ocn, hvs, kvp, M;
+    uint32_t hw, vhc, ocn, hvs, kvp, M, slots;
 };
 
 template <typename T, int EPI>
@@ -919,7 +719,7 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
         if (i >= I) continue;
         if constexpr (EPI == EPI_HEADCONV) {
             // i = head channel (value rows first), j = tower row b*64 + p
-            const uint32_t bb = j / SLOTS, p = j % SLOTS;
+            const uint32_t bb = j / ep.slots, p = j % ep.slots;
             if (i >= ep.ocn || p >= ep.hw) continue;
             const float y = acc[e] + ep.bias[i];
             const uint32_t col = i < ep.vhc ? i * ep.hw + p : ep.kvp + (i - ep.vhc) * ep.hw + p;
@@ -992,9 +792,10 @@ static void launch_head_gemm(Act act, const void* P, uint32_t ldp, uint32_t I, c
 void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, const HeadsMfma& hd, hipStream_t st) {
     HeadEpi ep{};
     ep.hw = hd.hw, ep.vhc = hd.vhc, ep.ocn = hd.vhc + hd.phc, ep.hvs = hd.kvp + hd.kpp, ep.kvp = hd.kvp, ep.M = hd.M;
+    ep.slots = hd.slots;
     // K3: both 1x1 convs in one GEMM: i = head channel, j = tower row
     ep.bias = hd.conv_b, ep.out = hd.hv;
-    launch_head_gemm<EPI_HEADCONV>(act, hd.conv_w, F, 32, tower, F, nb * SLOTS, F, ep, st);
+    launch_head_gemm<EPI_HEADCONV>(act, hd.conv_w, F, 32, tower, F, nb * hd.slots, F, ep, st);
     // K4 + K5 in one launch: value FC1 (+ReLU): i = leaf, j = hidden unit; policy FC: i = leaf, j = move
     const size_t esz = act == Act::BF16 ? 2 : 4;
     if (!nb) return;

@@ -25,7 +25,8 @@ pytestmark = pytest.mark.gpu
 # bf16 tower vs f32 oracle: |dlogit| <= BF16_POLICY_ATOL + BF16_POLICY_RTOL*|logit|, |dvalue| <= BF16_VALUE_ATOL
 BF16_POLICY_RTOL, BF16_POLICY_ATOL, BF16_VALUE_ATOL = 5e-2, 5e-2, 3e-2
 
-MFMA_SHAPES = ["hex7_6x64", "chess_2x64", "ttt_2x64", "chess_20x256"]
+# every fixture runs on the MFMA tower: filters are padded to 64 channels, boards above 8x8 take 128 pixel slots
+MFMA_SHAPES = golden_names()
 
 
 def _plane_words(planes):
@@ -82,10 +83,37 @@ def test_bf16_within_stated_tolerance(name):
     assert (np.abs(got_v - ref_v) <= BF16_VALUE_ATOL).all(), np.abs(got_v - ref_v).max()
 
 
-def test_bf16_rejected_for_shapes_without_mfma_kernel():
-    d, blob, z = blob_for("chess_7x16")
+@pytest.mark.parametrize("name", ["chess_7x16", "hex11_2x8", "ttt_5x8", "hex4_7x16", "hex11_1x1"])
+def test_mfma_tower_equals_generic_checker_on_the_reference_shapes(name, monkeypatch):
+    """The reference's own nets (7x16, 5x8 filters: training/config/*.yaml) and boards above 8x8
+    (training/tests/test_net_output.py:153-189) run on conv3x3_mfma_v2_kernel with zero-padded channels / 128-slot
+    boards; the one-thread-per-output kernel stays as a checker (CATTUS_FORCE_GENERIC=1): f32 results are equal
+    bit for bit, whatever the batch composition."""
+    d, blob, z = blob_for(name)
+    planes = z["planes"]
+    words = _plane_words(planes)
+    rep = np.concatenate([planes] * 3)[: len(planes) * 2 + 1]  # ragged: not a multiple of the boards per workgroup
+    monkeypatch.setenv("CATTUS_FORCE_GENERIC", "1")
+    with HipEvaluator(blob, batch_size=len(rep), plane_words=words, dtype="f32") as ev:
+        want_p, want_v = ev.eval(rep)
+    monkeypatch.delenv("CATTUS_FORCE_GENERIC")
+    with HipEvaluator(blob, batch_size=len(rep) + 7, plane_words=words, dtype="f32") as ev:
+        got_p, got_v = ev.eval(rep)
+        one_p, one_v = ev.eval(rep[-1:])
+    assert (got_p == want_p).all() and (got_v == want_v).all()
+    assert (one_p[0] == want_p[-1]).all() and one_v[0] == want_v[-1]
+
+
+def test_wide_heads_take_the_generic_path_and_refuse_bf16():
+    d = NetDesc(**hex_game(5), blocks=1, filters=32, vhc=24, phc=24)  # 48 head channels > one 32-row MFMA tile
+    blob = seeded_blob(d, 4)
+    planes = synth.random_hex_planes(5, 5, 2)
+    want_p, want_v = oracle.OracleNet(blob).forward(planes)
+    with HipEvaluator(blob, batch_size=8, plane_words=2, dtype="f32") as ev:
+        got_p, got_v = ev.eval(planes)
+    assert (got_p == want_p).all() and (got_v == want_v).all()
     with pytest.raises(CattusHipError) as ei:
-        HipEvaluator(blob, batch_size=4, plane_words=1, dtype="bf16")
+        HipEvaluator(blob, batch_size=4, plane_words=2, dtype="bf16")
     assert ei.value.status == -2
 
 

@@ -102,7 +102,7 @@ def test_device_softmax_games_equal_host_restatement(game, desc, words):
 @pytest.mark.parametrize("game,size", [("tictactoe", 3), ("hex4", 4), ("hex5", 5), ("hex7", 7), ("hex9", 9), ("hex11", 11), ("chess", 8)])
 def test_full_loop_smoke_every_game(game, size):
     """The reference's smoke loops (training/tests/test_convnetv1.py:10-58): every game with a tiny ConvNetV1,
-    sim_num 10, noise off -- here through the HIP evaluator (boards above 8x8 take the generic f32 tower) and
+    sim_num 10, noise off -- here through the HIP evaluator (16 filters padded to 64; boards above 8x8 on 128 pixel slots) and
     checked for well-formed records and against the same run on the CPU oracle network."""
     info = sp.game_info(game)
     d = NetDesc(planes=info["planes"], board=info["board"], moves=info["moves"], blocks=2, filters=16, vhc=4, phc=4)
