@@ -376,7 +376,7 @@ def main():
             elapsed2 = max_over_ranks(time.perf_counter() - t0)
             assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
         ev.close()
-        return elapsed, launch_us, launches, elapsed2, "conv3x3_mfma_v2_kernel"
+        return elapsed, launch_us, launches, elapsed2, "tower64_lds_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel"
 
     def roofline(dtype, launch_us, launches, kernel):
         flop_per_launch = d.conv_flops_per_position() * batch / launches

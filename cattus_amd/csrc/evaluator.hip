@@ -222,6 +222,10 @@ struct cattus_eval {
     uint32_t hw = 0, bpad = 0, cpad0 = 0;
     uint32_t slots = 64;  // pixel slots per board of the tuned tower (kernels.h: tower_slots)
     uint32_t fpad = 0;    // filters as laid out on the device: rounded up to 64 on the tuned path (zero channels)
+    // bf16 networks with <= 64 filters: the whole tower in one launch, activations resident in LDS
+    // (tower64_lds_kernel; CATTUS_TOWER64=0 selects the per-layer launches, for A/B runs and the equality test)
+    bool tower64 = false;
+    DevBuf t64_layers;
     int device = 0;
 
     ConvLayer stem;
@@ -382,6 +386,18 @@ int build(cattus_eval* e, const float* p) {
         e->kvp = kv, e->kpp = kp;
     }
 
+    if (e->tuned && e->act == Act::BF16 && FP == 64 && e->cpad0 == 64) {
+        const char* sw = getenv("CATTUS_TOWER64");
+        e->tower64 = !(sw && sw[0] == '0');
+        std::vector<Tower64Layer> tl;
+        tl.push_back(Tower64Layer{e->stem.w.p, e->stem.b.as<float>(), 0, 0});
+        for (uint32_t i = 0; i < d.blocks; i++) {
+            tl.push_back(Tower64Layer{e->c1[i]->w.p, e->c1[i]->b.as<float>(), 0, 0});
+            tl.push_back(Tower64Layer{e->c2[i]->w.p, e->c2[i]->b.as<float>(), 1, 0});
+        }
+        if ((rc = e->t64_layers.upload(tl.data(), tl.size() * sizeof(Tower64Layer)))) return rc;
+    }
+
     // activations
     const size_t bp_ = e->bpad, B = e->cfg.max_batch;
     const size_t esz = e->tuned ? (size_t)act_bytes(e->act) : 4;
@@ -430,8 +446,16 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         const uint32_t bpw = ROWS_PER_WG / e->slots;  // boards per workgroup of the conv kernel
         const uint32_t FP = e->fpad;
         nb = (n + bpw - 1) / bpw * bpw;
-        launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
-        {
+        if (e->tower64) {
+            Tower64Args ta{};
+            ta.planes = d_planes, ta.layers = e->t64_layers.as<Tower64Layer>(), ta.out = a;
+            ta.n = n, ta.C = d.planes, ta.w64 = w64, ta.S = S, ta.nlayers = 1 + 2 * d.blocks;
+            const uint32_t rows = nb * e->slots;
+            // 256-row workgroups once they fill the chip, else twice as many 128-row ones
+            hipEvent_t s0 = ev(false), s1 = ev(true);
+            launch_tower64(ta, rows, rows / ROWS_PER_WG >= 256 ? 1 : 2, st, s0, s1);
+        } else {
+            launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
             // every launch is told which weights come next, so that its idle loader waves can pull them into L2
             const size_t wbytes = (size_t)9 * FP * FP * act_bytes(e->act);
             auto next_w = [&](uint32_t block, int which) -> const void* {  // which: 0 = conv1, 1 = conv2 of `block`
@@ -882,7 +906,7 @@ CATTUS_API int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, 
     Lane& L = e->lanes[0];
     std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
-    const uint32_t per_fwd = 1 + 2 * e->d.blocks;
+    const uint32_t per_fwd = e->tower64 ? 1 : 1 + 2 * e->d.blocks;
     TowerTimer tt;
     tt.ev.resize((size_t)2 * per_fwd);
     for (auto& ev : tt.ev) HIP_TRY(hipEventCreate(&ev));

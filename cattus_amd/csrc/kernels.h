@@ -36,6 +36,23 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 // w_next (optional): weight tensor of the layer that runs next; the launch's idle loader waves pull it into L2.
 void set_conv_prefetch(bool on);
 
+// ---- K1 resident: whole tower of a network with <= 64 (padded) filters in one launch, bf16 (see kernels.hip) ----
+struct Tower64Layer {
+    const void* w;      // [9][64][64] bf16 (stem: input channels padded to 64)
+    const float* bias;  // [64]
+    int res;            // 1: add the block input (second conv of a residual block)
+    int pad_;
+};
+struct Tower64Args {
+    const uint64_t* planes;      // [n][C][w64] bitboards
+    const Tower64Layer* layers;  // device array [nlayers]: stem, then (conv1, conv2) per block
+    void* out;                   // [rows][64] bf16 tower output, rows = boards * tower_slots(S)
+    uint32_t n, C, w64, S, nlayers;
+};
+// rows % (256 / ch) == 0; ch = 1: 256 rows per workgroup, ch = 2: 128 rows per workgroup (small batches)
+void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, hipStream_t st, hipEvent_t ev_start = nullptr,
+                    hipEvent_t ev_stop = nullptr);
+
 // Generic f32 NCHW direct conv for shapes the MFMA kernel does not cover (any S <= 11, any C).
 // in [b][cin][hw], w [9][cout][cin], out [b][cout][hw]; same summation order as the MFMA f32 kernel.
 void launch_conv3x3_generic(const float* in, const float* w, const float* bias, const float* res, float* out,

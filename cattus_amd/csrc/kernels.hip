@@ -620,6 +620,275 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 resident: the whole tower of a <= 64-filter network in ONE launch, activations stay in LDS
+// ------------------------------------------------------------------------------------------
+//
+// With 64 (padded) filters there is a single output-channel slab, so the input of a workgroup's next layer
+// is its own output: nothing has to be handed to another workgroup, and nothing has to go through HBM.
+// The workgroup expands its boards' bitboard planes into LDS (the plane pack, fused), then runs stem +
+// 2 convs per residual block with the block input and the intermediate kept in two LDS buffers of
+// [rows][64 ch] bf16 (XOR-swizzled 128-byte rows, the conv kernel's layout), streaming only the weights:
+// waves 4-7 run the same LDS-DMA ring as in conv3x3_mfma_v2_kernel (3 slabs of [3 taps][64 cout][128 B]),
+// two steps ahead across layer boundaries; waves 0-3 are MFMA consumers.  One s_barrier per (layer, kernel
+// row) orders the ring and, at a layer boundary, one wave's LDS writes against its neighbours' reads.
+// Arithmetic per output element is that of the per-layer kernel, operation for operation (bf16 operands,
+// f32 accumulation in the same order, + bias, + skip, ReLU, one rounding to bf16), so results are bit-identical.
+//
+// CH = 1: 256 tower rows per workgroup, consumer wave w owns rows 64w..64w+63 x 64 couts (2x2 MFMA tiles).
+// CH = 2: 128 rows per workgroup (twice the workgroups: small batches), wave w owns row block w>>1 and the
+//         32 couts of half w&1 (1x2 tiles).
+// 2-byte activations only: f32 rows (2 chunks) would need 128 KiB besides the weight ring.
+constexpr int R_LDS_W = 0;                    // 3 x 24 KiB
+constexpr int R_LDS_ZERO = 3 * V2_SLAB;       // 128 B of zeros
+constexpr int R_LDS_ACT = R_LDS_ZERO + 128;   // 2 x ROWS x 128 B
+constexpr int tower64_lds_bytes(int ch) { return R_LDS_ACT + 2 * (256 / ch) * 128; }
+
+template <int CH, bool BIG>
+__global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
+    typedef __bf16 T;
+    typedef Mfma<T>::frag frag;
+    constexpr int ROWS = 256 / CH;      // tower rows of this workgroup
+    constexpr int CB = 2 / CH;          // 32-cout blocks per consumer wave
+    constexpr int ACT_BYTES = ROWS * 128;
+    constexpr int SLOTS_PER_BOARD = BIG ? 128 : 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const bool is_loader = wave >= 4;
+    const int S = (int)A.S;
+    const int row0 = blockIdx.x * ROWS;
+    const int nlayers = (int)A.nlayers;
+
+    if (tid < 8) reinterpret_cast<f32x4*>(smem + R_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- stem input: bitboard planes -> buffer 1, [row][64 ch], 1.0 where the plane has the pixel's bit ----
+    {
+        const int hw = S * S;
+        const uint32_t cslots = (A.C + 7) / 8;  // 16-byte channel groups that hold a real plane
+        for (int v = tid; v < ROWS * 8; v += 512) {
+            const int row = v >> 3, sl = v & 7;
+            const uint32_t grow = (uint32_t)(row0 + row);
+            const uint32_t board = grow / SLOTS_PER_BOARD, px = grow % SLOTS_PER_BOARD;
+            bf16x8 vals;
+#pragma unroll
+            for (int i = 0; i < 8; i++) vals[i] = (T)0.0f;
+            if ((uint32_t)sl < cslots && board < A.n && (int)px < hw) {
+                const uint64_t* pl = A.planes + (size_t)board * A.C * A.w64 + (px >> 6);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t c = sl * 8 + i;
+                    if (c < A.C && ((pl[(size_t)c * A.w64] >> (px & 63)) & 1ull)) vals[i] = (T)1.0f;
+                }
+            }
+            *reinterpret_cast<bf16x8*>(smem + R_LDS_ACT + ACT_BYTES + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4)) = vals;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave's first barrier
+    }
+
+    const int T_total = nlayers * 3;
+    if (is_loader) {
+        // ================================ loader waves: the weight stream ================================
+        const int lw = wave - 4;
+        const int prow = lane >> 3, pslot = lane & 7;
+        uint32_t off_w[WPL];
+        int dst_w[WPL];
+#pragma unroll
+        for (int i = 0; i < WPL; i++) {
+            const int pid = lw * WPL + i;  // 0..23: tap_i = pid/8, 8 rows each
+            const int tap_i = pid >> 3, row = (pid & 7) * 8 + prow;
+            const int c = pslot ^ ((row >> 1) & 7);
+            off_w[i] = ((uint32_t)(tap_i * 64 + row)) * 128 + c * 16;
+            dst_w[i] = pid * 1024;
+        }
+        auto issue_w = [&](int t) {  // weight slab of step t (layer t/3, kernel row t%3) -> ring slot t % 3
+            const int layer = t / 3, g = t - layer * 3;
+            const char* src = reinterpret_cast<const char*>(A.layers[layer].w) + (size_t)(g * 3) * 64 * 128;
+            char* dst = smem + R_LDS_W + g * V2_SLAB;
+#pragma unroll
+            for (int i = 0; i < WPL; i++) glds16(src + off_w[i], dst + dst_w[i]);
+        };
+        issue_w(0);
+        if (T_total > 1) issue_w(1);
+        for (int t = 0; t < T_total; t++) {
+            // step t's slab was issued two steps ago; only the slab of step t+1 may still be in flight
+            if (t + 1 < T_total) wait_vm_barrier<WPL>();
+            else wait_vm_barrier<0>();
+            if (t + 2 < T_total) issue_w(t + 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ================================ consumer waves ================================
+    const int r = lane & 31, h = lane >> 5;
+    const int rb = CH == 2 ? wave >> 1 : wave;             // 64-row block of this wave
+    const int coutb = CH == 2 ? (wave & 1) * 32 : 0;       // first output channel of this wave
+    const int pslot0 = BIG ? (rb & 1) * 64 : 0;
+    const int board_lds = BIG ? (rb >> 1) * 16384 : rb * 8192;
+    int ph[2], pw[2];
+    bool pvalid[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) {
+        const int p = pslot0 + pb * 32 + r;
+        ph[pb] = p / S;
+        pw[pb] = p - ph[pb] * S;
+        pvalid[pb] = p < S * S;
+    }
+    int aaddr[4][CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) {
+        const int row = coutb + cb * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) aaddr[ks][cb] = R_LDS_W + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4);
+    }
+    // LDS address of this lane's 4-cout group (cb, g4) in pixel row (pb) of a buffer: 8 bytes at
+    // row*128 + swizzled 16-byte slot of the cout + h*8
+    int eaddr[2];  // per pb: byte offset of the pixel row inside a buffer
+    int eswz[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) {
+        const int row = rb * 64 + pb * 32 + r;
+        eaddr[pb] = row * 128 + h * 8;
+        eswz[pb] = (row >> 1) & 7;
+    }
+
+    constexpr int AHEAD = 2, RING = 3;
+    int opaque = 0;
+    for (int layer = 0; layer < nlayers; layer++) {
+        const Tower64Layer L = A.layers[layer];
+        // buffers: the stem reads 1 and writes 0; a block's first conv reads 0 and writes 1, its second reads 1,
+        // adds 0 (the block input) and writes 0
+        const int in_buf = (layer & 1) ? 0 : 1;
+        const int ibase = R_LDS_ACT + in_buf * ACT_BYTES + board_lds;
+        const int obase = R_LDS_ACT + (1 - in_buf) * ACT_BYTES;
+        f32x4 biasv[CB][4];
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(L.bias + coutb + cb * 32 + g * 8 + h * 4);
+        f32x16 acc[CB][2];
+#pragma unroll
+        for (int i = 0; i < CB; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            // fragment reads of the previous step and (at a layer boundary) the previous layer's output writes
+            // are done before anybody passes: the loaders may reuse the slab, the neighbours may read the rows
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("" : "+v"(opaque));  // keeps the per-step addresses from being hoisted out of the layer loop
+            const int wslab = g * V2_SLAB;
+            int baddr[3][2][4];
+#pragma unroll
+            for (int dxi = 0; dxi < 3; dxi++)
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) {
+                    const int hh = ph[pb] + (g - 1) + opaque, ww = pw[pb] + dxi - 1;
+                    const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
+                    const int q = hh * S + ww;
+                    const int rowa = ok ? ibase + q * 128 : R_LDS_ZERO;
+                    const int x0 = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
+                }
+            frag fa[RING][CB], fb[RING][2];
+            auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[2]) {
+                const int dxi = i >> 2, ks = i & 3;
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+                    a[cb] = *reinterpret_cast<const frag*>(smem + aaddr[ks][cb] + (wslab + dxi * 8192));
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][ks]);
+            };
+#pragma unroll
+            for (int i = 0; i < AHEAD; i++) load_stage(i, fa[i % RING], fb[i % RING]);
+            __builtin_amdgcn_sched_group_barrier(0x100, (CB + 2) * AHEAD, 0);
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                if (i + AHEAD < 12) load_stage(i + AHEAD, fa[(i + AHEAD) % RING], fb[(i + AHEAD) % RING]);
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
+                if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, CB + 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CB * 2, 0);
+            }
+        }
+
+        // ---- layer epilogue: + bias (+ block input), ReLU, bf16, into the other buffer (same layout) ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int slot16 = (coutb >> 3) + cb * 4 + g;  // 16-byte slot of couts coutb + cb*32 + g*8 .. +7
+                    char* dst = smem + obase + eaddr[pb] + ((slot16 ^ eswz[pb]) << 4);
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + biasv[cb][g][i];
+                    if (L.res) {  // the block input lives in the buffer being overwritten: same address, read first
+                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(dst);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) v[i] = v[i] + (float)rv[i];
+                    }
+                    bf16x4 ov;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float y = v[i] > 0.0f ? v[i] : 0.0f;
+                        if (!pvalid[pb]) y = 0.0f;
+                        ov[i] = (T)y;
+                    }
+                    *reinterpret_cast<bf16x4*>(dst) = ov;
+                }
+    }
+
+    // ---- tower output: the last layer's buffer -> HBM [rows][64], whole 128-byte rows ----
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the loader waves have left: live waves only
+    {
+        const int fin = (nlayers & 1) ? 0 : 1;  // the stem and every second conv of a block write buffer 0
+        const int prow = lane >> 3, sl = lane & 7;
+        constexpr int RPW = 64 / CH;  // rows this wave stores
+        const int lrow0 = rb * 64 + (CH == 2 ? (wave & 1) * 32 : 0);
+        T* out = reinterpret_cast<T*>(A.out);
+#pragma unroll
+        for (int i = 0; i < RPW / 8; i++) {
+            const int row = lrow0 + i * 8 + prow;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + R_LDS_ACT + fin * ACT_BYTES + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4));
+            *reinterpret_cast<f32x4*>(out + ((size_t)row0 + row) * 64 + sl * 8) = v;
+        }
+    }
+}
+
+void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const bool big = tower_slots(args.S) == 128;
+#define CATTUS_LAUNCH_T64(CH, BIG)                                                                              \
+    do {                                                                                                        \
+        static std::atomic<uint64_t> attr_set{0};                                                               \
+        if (first_use_on_device(attr_set)) {                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower64_lds_kernel<CH, BIG>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, tower64_lds_bytes(CH));       \
+        }                                                                                                       \
+        hipExtLaunchKernelGGL((tower64_lds_kernel<CH, BIG>), dim3(rows / (256 / CH)), dim3(512), tower64_lds_bytes(CH), st, ev_start, \
+                              ev_stop, 0, args);                                                                \
+    } while (0)
+    if (ch == 2) {
+        if (big) CATTUS_LAUNCH_T64(2, true);
+        else CATTUS_LAUNCH_T64(2, false);
+    } else {
+        if (big) CATTUS_LAUNCH_T64(1, true);
+        else CATTUS_LAUNCH_T64(1, false);
+    }
+#undef CATTUS_LAUNCH_T64
+}
+
+// ------------------------------------------------------------------------------------------
 // K1g: generic direct conv, f32 NCHW, one thread per output element, canonical chain order
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) conv3x3_generic_kernel(const float* __restrict__ in, const float* __restrict__ w,

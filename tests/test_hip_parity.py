@@ -104,6 +104,40 @@ def test_mfma_tower_equals_generic_checker_on_the_reference_shapes(name, monkeyp
     assert (one_p[0] == want_p[-1]).all() and one_v[0] == want_v[-1]
 
 
+@pytest.mark.parametrize("game,desc,words,n", [
+    ("hex7", dict(**hex_game(7), blocks=6, filters=64, vhc=16, phc=16), 2, 128),    # BASELINE config 2: 128-row workgroups
+    ("hex7", dict(**hex_game(7), blocks=3, filters=64, vhc=16, phc=16), 2, 1100),   # 256-row workgroups, ragged batch
+    ("chess", dict(**CHESS, blocks=7, filters=16, vhc=8, phc=8), 1, 300),           # the reference's chess net, padded channels
+    ("hex11", dict(**hex_game(11), blocks=2, filters=8, vhc=4, phc=4), 2, 37),      # 128-slot boards
+    ("hex9", dict(**hex_game(9), blocks=2, filters=40, vhc=16, phc=16), 2, 600),    # 128-slot boards, 256-row workgroups
+    ("ttt", dict(planes=3, board=3, moves=9, blocks=5, filters=8, vhc=8, phc=8), 1, 5),
+])
+def test_resident_tower_equals_per_layer_launches(game, desc, words, n, monkeypatch):
+    """bf16 networks with <= 64 (padded) filters run their whole tower in one launch with the activations
+    resident in LDS (tower64_lds_kernel, plane pack fused); results are bit-identical to the per-layer
+    launches (CATTUS_TOWER64=0), for whole and ragged batches and after repeated passes."""
+    d = NetDesc(**desc)
+    blob = seeded_blob(d, 17)
+    rng = np.random.default_rng(5)
+    hw = d.board * d.board
+    planes = np.zeros((n, d.planes, words), dtype=np.uint64)
+    bits = rng.integers(0, 2, size=(n, d.planes, hw), dtype=np.uint64)
+    for i in range(hw):
+        planes[:, :, i >> 6] |= bits[:, :, i] << np.uint64(i & 63)
+    monkeypatch.setenv("CATTUS_TOWER64", "0")
+    with HipEvaluator(blob, batch_size=n, plane_words=words, dtype="bf16") as ev:
+        want_p, want_v = ev.eval(planes)
+    monkeypatch.delenv("CATTUS_TOWER64")
+    with HipEvaluator(blob, batch_size=n + 3, plane_words=words, dtype="bf16") as ev:
+        for _ in range(3):
+            got_p, got_v = ev.eval(planes)
+            assert (got_p == want_p).all() and (got_v == want_v).all()
+        k = max(1, n // 3)
+        sub_p, sub_v = ev.eval(planes[k : 2 * k + 1])
+        assert (sub_p == want_p[k : 2 * k + 1]).all() and (sub_v == want_v[k : 2 * k + 1]).all()
+        assert ev.time_tower(min(n, 8), 1)[1] == 1  # one tower launch per forward
+
+
 def test_wide_heads_take_the_generic_path_and_refuse_bf16():
     d = NetDesc(**hex_game(5), blocks=1, filters=32, vhc=24, phc=24)  # 48 head channels > one 32-row MFMA tile
     blob = seeded_blob(d, 4)
