@@ -332,7 +332,7 @@ int build(cattus_eval* e, const float* p) {
         if ((rc = upload_conv(e, *e->c2.back(), fold_conv(w2, F, F, 9, g2, be2, mu2, var2), F, F, FP, FP))) return rc;
     }
     // heads: value rows first, then policy rows, in one [vhc+phc][F] 1x1 conv
-    std::vector<float> hw_w((size_t)(d.vhc + d.phc) * F), hw_b(d.vhc + d.phc);
+    std::vector<float> hw_w((size_t)(d.vhc + d.phc) * F), hw_b(std::max(32u, d.vhc + d.phc), 0.0f);  // bias padded to one 32-row tile
     const float* vw = take((size_t)d.vhc * F);
     const float *vmu = take(d.vhc), *vvar = take(d.vhc);
     Folded fv = fold_conv(vw, d.vhc, F, 1, nullptr, nullptr, vmu, vvar);
@@ -448,12 +448,16 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         nb = (n + bpw - 1) / bpw * bpw;
         if (e->tower64) {
             Tower64Args ta{};
-            ta.planes = d_planes, ta.layers = e->t64_layers.as<Tower64Layer>(), ta.out = a;
+            ta.planes = d_planes, ta.layers = e->t64_layers.as<Tower64Layer>(), ta.out = nullptr;
             ta.n = n, ta.C = d.planes, ta.w64 = w64, ta.S = S, ta.nlayers = 1 + 2 * d.blocks;
+            ta.head_w = e->head_w.p, ta.head_b = e->head_b.as<float>(), ta.hv = L.hv.p;
+            ta.hvs = e->kvp + e->kpp, ta.kvp = e->kvp, ta.vhc = d.vhc, ta.ocn = d.vhc + d.phc;
             const uint32_t rows = nb * e->slots;
             // 256-row workgroups once they fill the chip, else twice as many 128-row ones
             hipEvent_t s0 = ev(false), s1 = ev(true);
-            launch_tower64(ta, rows, rows / ROWS_PER_WG >= 256 ? 1 : 2, st, s0, s1);
+            int ch = rows / ROWS_PER_WG >= 256 ? 1 : 2;
+            if (const char* force = getenv("CATTUS_T64_CH")) ch = atoi(force) == 1 ? 1 : 2;  // A/B runs
+            launch_tower64(ta, rows, ch, st, s0, s1);
         } else {
             launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
             // every launch is told which weights come next, so that its idle loader waves can pull them into L2
@@ -499,7 +503,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         hd.hw = hw, hd.vhc = d.vhc, hd.phc = d.phc, hd.kvp = e->kvp, hd.kpp = e->kpp, hd.M = d.moves;
         hd.w2 = e->w2.as<float>(), hd.b2 = e->b2.as<float>(), hd.value = d_value;
         hd.slots = e->slots;
-        launch_heads_mfma(e->act, a, n, e->fpad, hd, st);
+        launch_heads_mfma(e->act, e->tower64 ? nullptr : a, n, e->fpad, hd, st);
     } else {
         TowerView tv;
         tv.x = a, tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;

@@ -46,8 +46,14 @@ struct Tower64Layer {
 struct Tower64Args {
     const uint64_t* planes;      // [n][C][w64] bitboards
     const Tower64Layer* layers;  // device array [nlayers]: stem, then (conv1, conv2) per block
-    void* out;                   // [rows][64] bf16 tower output, rows = boards * tower_slots(S)
+    void* out;                   // optional: [rows][64] bf16 tower output, rows = boards * tower_slots(S)
     uint32_t n, C, w64, S, nlayers;
+    // optional, fused K3: the two 1x1 head convs (+ folded BN + ReLU) on the resident tower output, written in the
+    // layout the head FC kernels read (HeadsMfma::hv)
+    const void* head_w;   // [32][64] bf16, value rows first, rows >= ocn zero
+    const float* head_b;  // [32]: entries >= ocn are not used
+    void* hv;             // [boards][hvs] bf16
+    uint32_t hvs, kvp, vhc, ocn;
 };
 // rows % (256 / ch) == 0; ch = 1: 256 rows per workgroup, ch = 2: 128 rows per workgroup (small batches)
 void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, hipStream_t st, hipEvent_t ev_start = nullptr,

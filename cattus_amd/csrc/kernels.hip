@@ -639,9 +639,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 //         32 couts of half w&1 (1x2 tiles).
 // 2-byte activations only: f32 rows (2 chunks) would need 128 KiB besides the weight ring.
 constexpr int R_LDS_W = 0;                    // 3 x 24 KiB
-constexpr int R_LDS_ZERO = 3 * V2_SLAB;       // 128 B of zeros
-constexpr int R_LDS_ACT = R_LDS_ZERO + 128;   // 2 x ROWS x 128 B
-constexpr int tower64_lds_bytes(int ch) { return R_LDS_ACT + 2 * (256 / ch) * 128; }
+constexpr int R_LDS_ACT = 3 * V2_SLAB;        // 2 x (ROWS x 128 B + a 128-byte zero row behind them)
+constexpr int tower64_lds_bytes(int ch) { return R_LDS_ACT + 2 * ((256 / ch) * 128 + 128); }
 
 template <int CH, bool BIG>
 __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
@@ -649,7 +648,8 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     typedef Mfma<T>::frag frag;
     constexpr int ROWS = 256 / CH;      // tower rows of this workgroup
     constexpr int CB = 2 / CH;          // 32-cout blocks per consumer wave
-    constexpr int ACT_BYTES = ROWS * 128;
+    constexpr int ZERO_OFF = ROWS * 128;       // the zero row of a buffer (padding pixels read it), behind its rows
+    constexpr int ACT_BYTES = ZERO_OFF + 128;  // buffer stride
     constexpr int SLOTS_PER_BOARD = BIG ? 128 : 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -660,40 +660,25 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     const int S = (int)A.S;
     const int row0 = blockIdx.x * ROWS;
     const int nlayers = (int)A.nlayers;
+    STAMP_DECL;
+    STAMP(0);
 
-    if (tid < 8) reinterpret_cast<f32x4*>(smem + R_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- stem input: bitboard planes -> buffer 1, [row][64 ch], 1.0 where the plane has the pixel's bit ----
-    {
-        const int hw = S * S;
-        const uint32_t cslots = (A.C + 7) / 8;  // 16-byte channel groups that hold a real plane
-        for (int v = tid; v < ROWS * 8; v += 512) {
-            const int row = v >> 3, sl = v & 7;
-            const uint32_t grow = (uint32_t)(row0 + row);
-            const uint32_t board = grow / SLOTS_PER_BOARD, px = grow % SLOTS_PER_BOARD;
-            bf16x8 vals;
-#pragma unroll
-            for (int i = 0; i < 8; i++) vals[i] = (T)0.0f;
-            if ((uint32_t)sl < cslots && board < A.n && (int)px < hw) {
-                const uint64_t* pl = A.planes + (size_t)board * A.C * A.w64 + (px >> 6);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t c = sl * 8 + i;
-                    if (c < A.C && ((pl[(size_t)c * A.w64] >> (px & 63)) & 1ull)) vals[i] = (T)1.0f;
-                }
-            }
-            *reinterpret_cast<bf16x8*>(smem + R_LDS_ACT + ACT_BYTES + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4)) = vals;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave's first barrier
-    }
+    if (tid < 16) reinterpret_cast<f32x4*>(smem + R_LDS_ACT + (tid >> 3) * ACT_BYTES + ZERO_OFF)[tid & 7] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int T_total = nlayers * 3;
+    // the loader waves put the first two weight slabs on their way before they help with the plane expansion
+    const int lw = wave - 4;
+    uint32_t off_w[WPL];
+    int dst_w[WPL];
+    auto issue_w = [&](int t) {  // weight slab of step t (layer t/3, kernel row t%3) -> ring slot t % 3
+        const int layer = t / 3, g = t - layer * 3;
+        const char* src = reinterpret_cast<const char*>(A.layers[layer].w) + (size_t)(g * 3) * 64 * 128;
+        char* dst = smem + R_LDS_W + g * V2_SLAB;
+#pragma unroll
+        for (int i = 0; i < WPL; i++) glds16(src + off_w[i], dst + dst_w[i]);
+    };
     if (is_loader) {
-        // ================================ loader waves: the weight stream ================================
-        const int lw = wave - 4;
         const int prow = lane >> 3, pslot = lane & 7;
-        uint32_t off_w[WPL];
-        int dst_w[WPL];
 #pragma unroll
         for (int i = 0; i < WPL; i++) {
             const int pid = lw * WPL + i;  // 0..23: tap_i = pid/8, 8 rows each
@@ -702,15 +687,48 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
             off_w[i] = ((uint32_t)(tap_i * 64 + row)) * 128 + c * 16;
             dst_w[i] = pid * 1024;
         }
-        auto issue_w = [&](int t) {  // weight slab of step t (layer t/3, kernel row t%3) -> ring slot t % 3
-            const int layer = t / 3, g = t - layer * 3;
-            const char* src = reinterpret_cast<const char*>(A.layers[layer].w) + (size_t)(g * 3) * 64 * 128;
-            char* dst = smem + R_LDS_W + g * V2_SLAB;
-#pragma unroll
-            for (int i = 0; i < WPL; i++) glds16(src + off_w[i], dst + dst_w[i]);
-        };
         issue_w(0);
         if (T_total > 1) issue_w(1);
+    }
+
+    // ---- stem input: bitboard planes -> buffer 1, [row][64 ch], 1.0 where the plane has the pixel's bit ----
+    {
+        const int hw = S * S;
+        const uint32_t cslots = (A.C + 7) / 8;  // 16-byte channel groups that hold a real plane
+        constexpr int ITEMS = ROWS * 8 / 512;   // (row, channel group) pairs per thread
+        typedef const __attribute__((address_space(1))) uint64_t* gu64p;
+        // all plane words first (one round trip to memory for the whole expansion), then the rows
+        uint64_t words[ITEMS][8];
+        bool live[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+            const int v = tid + it * 512;
+            const int row = v >> 3, sl = v & 7;
+            const uint32_t grow = (uint32_t)(row0 + row);
+            const uint32_t board = grow / SLOTS_PER_BOARD, px = grow % SLOTS_PER_BOARD;
+            live[it] = (uint32_t)sl < cslots && board < A.n && (int)px < hw;
+            const gu64p pl = (gu64p)(A.planes + (size_t)(live[it] ? board : 0) * A.C * A.w64 + (live[it] ? (px >> 6) : 0));
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t c = sl * 8 + i;
+                words[it][i] = (live[it] && c < A.C) ? pl[(size_t)c * A.w64] : 0ull;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+            const int v = tid + it * 512;
+            const int row = v >> 3, sl = v & 7;
+            const uint32_t px = (uint32_t)(row0 + row) % SLOTS_PER_BOARD;
+            bf16x8 vals;
+#pragma unroll
+            for (int i = 0; i < 8; i++) vals[i] = ((words[it][i] >> (px & 63)) & 1ull) ? (T)1.0f : (T)0.0f;
+            *reinterpret_cast<bf16x8*>(smem + R_LDS_ACT + ACT_BYTES + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4)) = vals;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave's first barrier
+    }
+
+    if (is_loader) {
+        // ================================ loader waves: the weight stream ================================
         for (int t = 0; t < T_total; t++) {
             // step t's slab was issued two steps ago; only the slab of step t+1 may still be in flight
             if (t + 1 < T_total) wait_vm_barrier<WPL>();
@@ -727,14 +745,26 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     const int coutb = CH == 2 ? (wave & 1) * 32 : 0;       // first output channel of this wave
     const int pslot0 = BIG ? (rb & 1) * 64 : 0;
     const int board_lds = BIG ? (rb >> 1) * 16384 : rb * 8192;
-    int ph[2], pw[2];
+    // Activation fragment addresses, relative to the input buffer: per (kernel row, tap column, pixel block) the
+    // byte offset of the shifted pixel's row (the buffer's zero row for pixels off the board) and the row's
+    // swizzle term.  They depend on nothing but the lane, so they are made once; a step adds the buffer base.
     bool pvalid[2];
+    int rel[3][3][2], swz[3][3][2];
 #pragma unroll
     for (int pb = 0; pb < 2; pb++) {
         const int p = pslot0 + pb * 32 + r;
-        ph[pb] = p / S;
-        pw[pb] = p - ph[pb] * S;
+        const int ph = p / S, pw = p - ph * S;
         pvalid[pb] = p < S * S;
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+#pragma unroll
+            for (int dxi = 0; dxi < 3; dxi++) {
+                const int hh = ph + g - 1, ww = pw + dxi - 1;
+                const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
+                const int q = hh * S + ww;
+                rel[g][dxi][pb] = ok ? board_lds + q * 128 : ZERO_OFF;
+                swz[g][dxi][pb] = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
+            }
     }
     int aaddr[4][CB];
 #pragma unroll
@@ -754,20 +784,35 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
         eswz[pb] = (row >> 1) & 7;
     }
 
-    constexpr int AHEAD = 2, RING = 3;
+    // fragments are read AHEAD stages before the MFMAs that use them; a stage is CB * 2 MFMAs
+    constexpr int AHEAD = CB == 2 ? 2 : 3, RING = AHEAD + 1;
     int opaque = 0;
+    frag wa[4];       // head conv weights of this lane's head channel row
+    f32x4 hbias[4];   // head conv bias of the 16 head channels this lane's accumulator holds
     for (int layer = 0; layer < nlayers; layer++) {
         const Tower64Layer L = A.layers[layer];
         // buffers: the stem reads 1 and writes 0; a block's first conv reads 0 and writes 1, its second reads 1,
         // adds 0 (the block input) and writes 0
         const int in_buf = (layer & 1) ? 0 : 1;
-        const int ibase = R_LDS_ACT + in_buf * ACT_BYTES + board_lds;
+        const int ibase = R_LDS_ACT + in_buf * ACT_BYTES;
         const int obase = R_LDS_ACT + (1 - in_buf) * ACT_BYTES;
+        // L.bias comes out of a table in memory, so the compiler cannot tell its address space: loaded through a
+        // generic pointer these would be FLAT loads, which count in lgkmcnt as well and return out of order -- while
+        // they are in flight (until the epilogue) every wait for an LDS fragment would have to be lgkmcnt(0).
+        typedef const __attribute__((address_space(1))) f32x4* gf32x4p;
+        const gf32x4p gbias = (gf32x4p)(L.bias + coutb + h * 4);
         f32x4 biasv[CB][4];
 #pragma unroll
         for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(L.bias + coutb + cb * 32 + g * 8 + h * 4);
+            for (int g = 0; g < 4; g++) biasv[cb][g] = gbias[cb * 8 + g * 2];
+        if (layer == nlayers - 1 && A.head_w) {  // operands of the fused head convs: on their way under the last layer
+            const T* hw_ = reinterpret_cast<const T*>(A.head_w);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) wa[ks] = *reinterpret_cast<const frag*>(hw_ + r * 64 + ks * 16 + h * 8);
+#pragma unroll
+            for (int q = 0; q < 4; q++) hbias[q] = *reinterpret_cast<const f32x4*>(A.head_b + 8 * q + 4 * h);
+        }
         f32x16 acc[CB][2];
 #pragma unroll
         for (int i = 0; i < CB; i++)
@@ -780,7 +825,12 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
         for (int g = 0; g < 3; g++) {
             // fragment reads of the previous step and (at a layer boundary) the previous layer's output writes
             // are done before anybody passes: the loaders may reuse the slab, the neighbours may read the rows
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            {
+                STAMP_ACC_BEGIN;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                STAMP_ACC_END(4);
+            }
+            if (layer == 0 && g == 0) STAMP(1);
             asm volatile("" : "+v"(opaque));  // keeps the per-step addresses from being hoisted out of the layer loop
             const int wslab = g * V2_SLAB;
             int baddr[3][2][4];
@@ -788,13 +838,9 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
             for (int dxi = 0; dxi < 3; dxi++)
 #pragma unroll
                 for (int pb = 0; pb < 2; pb++) {
-                    const int hh = ph[pb] + (g - 1) + opaque, ww = pw[pb] + dxi - 1;
-                    const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
-                    const int q = hh * S + ww;
-                    const int rowa = ok ? ibase + q * 128 : R_LDS_ZERO;
-                    const int x0 = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
+                    const int rowa = ibase + rel[g][dxi][pb] + opaque;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
+                    for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (swz[g][dxi][pb] ^ (ks << 5));
                 }
             frag fa[RING][CB], fb[RING][2];
             auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[2]) {
@@ -821,7 +867,11 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
         }
 
         // ---- layer epilogue: + bias (+ block input), ReLU, bf16, into the other buffer (same layout) ----
+        // Pixel slots >= S*S are stored as they come: no conv ever reads them as a neighbour (the address table
+        // sends off-board taps to the zero row) and the heads skip them.
+        STAMP_ACC_BEGIN;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int eoff[CB][2][4];
 #pragma unroll
         for (int cb = 0; cb < CB; cb++)
 #pragma unroll
@@ -829,30 +879,95 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int slot16 = (coutb >> 3) + cb * 4 + g;  // 16-byte slot of couts coutb + cb*32 + g*8 .. +7
-                    char* dst = smem + obase + eaddr[pb] + ((slot16 ^ eswz[pb]) << 4);
-                    float v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + biasv[cb][g][i];
-                    if (L.res) {  // the block input lives in the buffer being overwritten: same address, read first
-                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(dst);
-#pragma unroll
-                        for (int i = 0; i < 4; i++) v[i] = v[i] + (float)rv[i];
-                    }
-                    bf16x4 ov;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        float y = v[i] > 0.0f ? v[i] : 0.0f;
-                        if (!pvalid[pb]) y = 0.0f;
-                        ov[i] = (T)y;
-                    }
-                    *reinterpret_cast<bf16x4*>(dst) = ov;
+                    eoff[cb][pb][g] = obase + eaddr[pb] + ((slot16 ^ eswz[pb]) << 4);
                 }
+        // two code paths (uniform branch), packed f32 arithmetic: the MFMA pipes idle during an epilogue, so its
+        // instruction count is what it costs
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        auto finish = [&](const f32x16& a, int g, const f32x4& bv, const f32x2& r01, const f32x2& r23) {
+            f32x2 v01 = f32x2{a[g * 4 + 0], a[g * 4 + 1]} + f32x2{bv[0], bv[1]};
+            f32x2 v23 = f32x2{a[g * 4 + 2], a[g * 4 + 3]} + f32x2{bv[2], bv[3]};
+            v01 = v01 + r01;
+            v23 = v23 + r23;
+            v01 = __builtin_elementwise_max(v01, f32x2{0.0f, 0.0f});
+            v23 = __builtin_elementwise_max(v23, f32x2{0.0f, 0.0f});
+            bf16x4 ov;
+            ov[0] = (T)v01[0], ov[1] = (T)v01[1], ov[2] = (T)v23[0], ov[3] = (T)v23[1];
+            return ov;
+        };
+        if (L.res) {  // the block input lives in the buffer being overwritten: same addresses, all read first
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            u32x2 rv[CB][2][4];
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) rv[cb][pb][g] = *reinterpret_cast<const u32x2*>(smem + eoff[cb][pb][g]);
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const u32x2 w = rv[cb][pb][g];  // 4 bf16: a bf16 is the high half of the f32 with the same value
+                        const f32x2 r01{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u)};
+                        const f32x2 r23{__uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+                        *reinterpret_cast<bf16x4*>(smem + eoff[cb][pb][g]) = finish(acc[cb][pb], g, biasv[cb][g], r01, r23);
+                    }
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        // adding +0.0 leaves every value as it is (x + 0 == x, also for -0 + +0 = +0 before the ReLU)
+                        *reinterpret_cast<bf16x4*>(smem + eoff[cb][pb][g]) =
+                            finish(acc[cb][pb], g, biasv[cb][g], f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f});
+                    }
+        }
+        STAMP_ACC_END(5);
     }
+    STAMP(2);
 
-    // ---- tower output: the last layer's buffer -> HBM [rows][64], whole 128-byte rows ----
+    // ---- the two 1x1 head convs on the resident tower output (K3 fused; same MFMA order as head_gemm_tile) ----
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the loader waves have left: live waves only
-    {
-        const int fin = (nlayers & 1) ? 0 : 1;  // the stem and every second conv of a block write buffer 0
+    const int fin = (nlayers & 1) ? 0 : 1;  // the stem and every second conv of a block write buffer 0
+    if (A.head_w) {
+        // D[i][px] = sum_k W[i][k] * X[px][k]: A = head weights [32][64] (rows >= ocn are zero), B = tower rows.
+        // CH = 1: the wave covers its 64 rows (2 pixel blocks); CH = 2: the two waves of a row block take one each.
+        constexpr int NPB = CH == 2 ? 1 : 2;
+        const int hwp = S * S;
+#pragma unroll
+        for (int pbi = 0; pbi < NPB; pbi++) {
+            const int pb = CH == 2 ? (wave & 1) : pbi;
+            const int row = rb * 64 + pb * 32 + r;
+            f32x16 hacc;
+#pragma unroll
+            for (int e = 0; e < 16; e++) hacc[e] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const frag xb = *reinterpret_cast<const frag*>(smem + R_LDS_ACT + fin * ACT_BYTES + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4));
+                Mfma<T>::mac(wa[ks], xb, hacc);
+            }
+            const uint32_t grow = (uint32_t)(row0 + row);
+            const uint32_t bb = grow / SLOTS_PER_BOARD, p = grow % SLOTS_PER_BOARD;
+            if ((int)p < hwp) {
+                T* hvrow = reinterpret_cast<T*>(A.hv) + (size_t)bb * A.hvs;
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const uint32_t i = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (i >= A.ocn) continue;
+                    const float y = hacc[e] + hbias[e >> 2][e & 3];
+                    const uint32_t col = i < A.vhc ? i * hwp + p : A.kvp + (i - A.vhc) * hwp + p;
+                    hvrow[col] = (T)(y > 0.0f ? y : 0.0f);
+                }
+            }
+        }
+    }
+    // ---- optional: the tower output itself -> HBM [rows][64], whole 128-byte rows ----
+    if (A.out) {
         const int prow = lane >> 3, sl = lane & 7;
         constexpr int RPW = 64 / CH;  // rows this wave stores
         const int lrow0 = rb * 64 + (CH == 2 ? (wave & 1) * 32 : 0);
@@ -864,6 +979,8 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
             *reinterpret_cast<f32x4*>(out + ((size_t)row0 + row) * 64 + sl * 8) = v;
         }
     }
+    STAMP(3);
+    STAMP_FLUSH(wave);
 }
 
 void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -1062,9 +1179,10 @@ void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, cons
     HeadEpi ep{};
     ep.hw = hd.hw, ep.vhc = hd.vhc, ep.ocn = hd.vhc + hd.phc, ep.hvs = hd.kvp + hd.kpp, ep.kvp = hd.kvp, ep.M = hd.M;
     ep.slots = hd.slots;
-    // K3: both 1x1 convs in one GEMM: i = head channel, j = tower row
+    // K3: both 1x1 convs in one GEMM: i = head channel, j = tower row (tower == nullptr: hv was already written
+    // by the resident tower kernel, which fuses this step)
     ep.bias = hd.conv_b, ep.out = hd.hv;
-    launch_head_gemm<EPI_HEADCONV>(act, hd.conv_w, F, 32, tower, F, nb * hd.slots, F, ep, st);
+    if (tower) launch_head_gemm<EPI_HEADCONV>(act, hd.conv_w, F, 32, tower, F, nb * hd.slots, F, ep, st);
     // K4 + K5 in one launch: value FC1 (+ReLU): i = leaf, j = hidden unit; policy FC: i = leaf, j = move
     const size_t esz = act == Act::BF16 ? 2 : 4;
     if (!nb) return;

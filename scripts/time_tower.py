@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Event-stamped tower launch duration of bench workloads: python scripts/time_tower.py [--warm REPS] WORKLOAD..."""
+import sys
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+from cattus_amd.evaluator import HipEvaluator  # noqa: E402
+
+args = sys.argv[1:]
+warm = 20
+if args and args[0] == "--warm":
+    warm, args = int(args[1]), args[2:]
+for wl in args:
+    d, blob, planes = bench.make_workload(wl)
+    ev = HipEvaluator(blob, batch_size=len(planes), plane_words=planes.shape[2], dtype="bf16")
+    ev.time_tower(len(planes), warm)
+    us, launches = ev.time_tower(len(planes), 200)
+    print(wl, "tower launch us:", round(us, 2), "x", launches, end="  |  ")
+    ev.close()
+print()
