@@ -358,13 +358,17 @@ def main():
         if lanes == 2:
             # the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
             # driver runs the evaluator: one batch's kernel tails overlap the other's heads
-            side = torch.cuda.Stream(device=dev)
             d_policy2, d_value2 = torch.empty_like(d_policy), torch.empty_like(d_value)
-            both = [(0, stream, d_policy, d_value), (1, side, d_policy2, d_value2)]
+            which = os.environ.get("BENCH_LANE_STREAMS", "lane")  # the evaluator's own lane streams, or two torch streams
+            if which == "torch":
+                handles = [stream.cuda_stream, torch.cuda.Stream(device=dev).cuda_stream]
+            else:
+                handles = [ev.lane_stream(0), ev.lane_stream(1)]
+            both = [(0, handles[0], d_policy, d_value), (1, handles[1], d_policy2, d_value2)]
 
             def step2(i):
                 lane, st, pol, val = both[i & 1]
-                ev.eval_device(d_planes.data_ptr(), batch, pol.data_ptr(), val.data_ptr(), st.cuda_stream, lane=lane)
+                ev.eval_device(d_planes.data_ptr(), batch, pol.data_ptr(), val.data_ptr(), st, lane=lane)
 
             for i in range(max(2, warmup // 2 * 2)):
                 step2(i)

@@ -460,22 +460,13 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             launch_tower64(ta, rows, ch, st, s0, s1);
         } else {
             launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
-            // every launch is told which weights come next, so that its idle loader waves can pull them into L2
-            const size_t wbytes = (size_t)9 * FP * FP * act_bytes(e->act);
-            auto next_w = [&](uint32_t block, int which) -> const void* {  // which: 0 = conv1, 1 = conv2 of `block`
-                if (block >= d.blocks) return nullptr;
-                return which == 0 ? e->c1[block]->w.p : e->c2[block]->w.p;
-            };
             hipEvent_t s0 = ev(false), s1 = ev(true);
-            launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
-                                next_w(0, 0), wbytes);
+            launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1);
             for (uint32_t i = 0; i < d.blocks; i++) {
                 s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1,
-                                    next_w(i, 1), wbytes);
+                launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1);
                 s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1,
-                                    next_w(i + 1, 0), wbytes);
+                launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1);
                 std::swap(a, y);
             }
         }
@@ -697,7 +688,6 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if (cfg->device < 0 || cfg->device >= ndev) return fail(CATTUS_E_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
     const char* wait_mode = getenv("CATTUS_HIP_WAIT");
-    if (const char* pf = getenv("CATTUS_PREFETCH")) set_conv_prefetch(atoi(pf) != 0);
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
     if (!e) return fail(CATTUS_E_NOMEM, "out of memory");

@@ -31,10 +31,7 @@ void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C
 // ev_start / ev_stop (optional): events stamped with the kernel's own begin / end time.
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
-                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const void* w_next = nullptr,
-                         size_t w_next_bytes = 0);
-// w_next (optional): weight tensor of the layer that runs next; the launch's idle loader waves pull it into L2.
-void set_conv_prefetch(bool on);
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- K1 resident: whole tower of a network with <= 64 (padded) filters in one launch, bf16 (see kernels.hip) ----
 struct Tower64Layer {

@@ -240,8 +240,7 @@ constexpr int APL = 16 / NLOAD;  // activation pieces per loader wave and half-c
 template <typename T, bool HAS_RES, bool BIG>
 __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S,
-                           const char* __restrict__ w_next, int w_next_lines) {
+                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S) {
     constexpr int KC = 128 / (int)sizeof(T);
     typedef typename Mfma<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -311,37 +310,13 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         issue_a(0, 1);
         issue_w(0);
         issue_w(1);
-        // Next layer's weights -> this XCD's L2.  The next launch starts cold: its 256 workgroups all ask for their
-        // first weight slabs at once and wait ~2 us for them to come from HBM / the Infinity Cache.  The loader waves
-        // are idle at the tail of this launch, so behind their last DMA each of them touches one 128-byte line per
-        // lane of the next layer's weight tensor; the workgroups observed on one XCD (equal blockIdx % 8) cover the
-        // whole tensor between them.  Placement is only a speed assumption: the loads are never read.
-        constexpr int PF = 2;  // prefetch loads per loader wave
-        const bool do_pf = w_next != nullptr;
-        int pf_younger = 0;  // prefetch loads in flight, younger than every DMA
-        // destination registers of the prefetch loads: written when the loads return, so they stay reserved
-        // (see the empty asm behind the final wait) although nothing reads them
-        unsigned pf_sink[PF] = {0, 0};
-        auto prefetch_next = [&]() {
-            const int nslots = max(1, (int)gridDim.x >> 3);
-            const int my = ((int)blockIdx.x >> 3) * NLOAD + lw, nw = nslots * NLOAD;
-#pragma unroll
-            for (int j = 0; j < PF; j++) {
-                int line = (j * nw + my) * 64 + lane;
-                if (line >= w_next_lines) line = lane % max(1, w_next_lines);
-                const char* p = w_next + (size_t)line * 128;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink[j]) : "v"(p) : "memory");
-            }
-        };
         int pending = WPL;  // loads issued after the data of the upcoming step
         for (int t = 0; t < T_total; t++) {
 #ifdef CATTUS_STAMPS
             {  // diagnostic build: time the wait for the data (slot 4) and the wait at the barrier (slot 7) apart
                 const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
                 if (pending == WPL + APL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPL + APL) : "memory");
-                else if (pending == WPL + PF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPL + PF) : "memory");
                 else if (pending == WPL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPL) : "memory");
-                else if (pending == PF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
                 asm volatile("s_barrier" ::: "memory");
@@ -350,13 +325,11 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             }
 #else
             if (pending == WPL + APL) wait_vm_barrier<WPL + APL>();
-            else if (pending == WPL + PF) wait_vm_barrier<WPL + PF>();
             else if (pending == WPL) wait_vm_barrier<WPL>();
-            else if (pending == PF) wait_vm_barrier<PF>();
             else wait_vm_barrier<0>();
 #endif
             if (t == 0) STAMP(1);
-            pending = pf_younger;
+            pending = 0;
             const int ch = t / 3, g = t - ch * 3;
             if (t + 2 < T_total) {
                 issue_w(t + 2);
@@ -366,14 +339,8 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 issue_a(ch + 1, g);
                 pending += APL;
             }
-            if (do_pf && t + 3 == T_total) {  // behind the last DMA of this launch
-                prefetch_next();
-                pf_younger = PF;
-                pending += PF;
-            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" ::"v"(pf_sink[0]), "v"(pf_sink[1]));
         STAMP(2);
         STAMP(3);
         STAMP_RT(6);
@@ -583,14 +550,9 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 }
 #endif
 
-bool g_conv_prefetch = true;  // loader waves pull the next layer's weights into L2 (A/B switch: CATTUS_PREFETCH=0)
-void set_conv_prefetch(bool on) { g_conv_prefetch = on; }
-
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st, hipEvent_t ev_start,
-                         hipEvent_t ev_stop, const void* w_next, size_t w_next_bytes) {
-    const char* wn = g_conv_prefetch ? (const char*)w_next : nullptr;
-    const int wn_lines = (int)(w_next_bytes / 128);
+                         hipEvent_t ev_stop) {
     const uint32_t slots = tower_slots(S);
     const dim3 grid((bpad * slots / ROWS_PER_WG) * (cout / COUT_PER_WG));
 #define CATTUS_LAUNCH_CONV2(T, R, BIG)                                                                    \
@@ -601,7 +563,7 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
         }                                                                                                 \
         hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                              (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, wn, wn_lines); \
+                              (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S); \
     } while (0)
 #define CATTUS_LAUNCH_CONV2_T(T)                             \
     do {                                                     \

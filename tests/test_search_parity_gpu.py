@@ -31,8 +31,10 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 # floors for statement 3; measured values go to gpurun_out/search_agreement.json
-BF16_MOVE_AGREEMENT_MIN = 0.75
-BF16_VISIT_L1_MEAN_MAX = 0.25
+# measured (round 2, 256 searched plies): agreement 0.941, L1 mean 0.0037, p95 0.015, max 0.045
+BF16_MOVE_AGREEMENT_MIN = 0.88
+BF16_VISIT_L1_MEAN_MAX = 0.015
+BF16_VISIT_L1_MAX = 0.12
 
 
 def _positions_of(lines, upto):
@@ -67,7 +69,7 @@ def test_chess_20x256_search_f32_equals_oracle_and_bf16_agreement_is_bounded():
         opens = ag.random_openings("chess", games, 2, seed=7)
         ta = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev32), opens, 2, plies)
         lines = [op + [chosen for chosen, _ in t] for op, t in zip(opens, ta)]
-        assert all(len(t) == plies for t in ta)
+        assert sum(len(t) for t in ta) >= games * plies - 8  # a game may end inside the window
         for t in ta:
             for _, visits in t:
                 assert sum(n for _, n in visits) >= sims - 1  # fresh tree: sims-1; a reused subtree starts with more
@@ -91,6 +93,9 @@ def test_chess_20x256_search_f32_equals_oracle_and_bf16_agreement_is_bounded():
     out.mkdir(exist_ok=True)
     (out / "search_agreement.json").write_text(json.dumps(res, indent=1))
     print("bf16 vs f32 search agreement:", json.dumps(res))
-    assert res["plies"] == games * plies
+    assert res["plies"] >= games * plies - 8
     assert res["move_agreement"] >= BF16_MOVE_AGREEMENT_MIN, res
     assert res["visit_l1_mean"] <= BF16_VISIT_L1_MEAN_MAX, res
+    assert res["visit_l1_max"] <= BF16_VISIT_L1_MAX, res
+    # where the two searches chose differently, bf16's own favourite had barely more visits than f32's move
+    assert res["b_visits_on_a_move_vs_b_best_mean"] >= 0.97, res
