@@ -189,8 +189,8 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
         "avg_launch_us": us,
         "leaves_per_launch": leaves,
         "bytes_per_leaf": 4752,
-        "note": "stand-alone planes_to_tensor drop-in (cattus_hip_planes_to_tensor_device, reference layout); the forward pass "
-                "feeds its stem from pack_planes_nhwc_kernel instead (one launch of ~5 us at batch 256, launch-bound)",
+        "note": "stand-alone planes_to_tensor drop-in (cattus_hip_planes_to_tensor_device, reference layout); inside the forward pass "
+                "the planes are expanded by the stem conv's loader waves straight into LDS (no separate launch, no packed tensor in HBM)",
     }
 
 
@@ -217,7 +217,9 @@ def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, ma
     from cattus_amd import selfplay as sp
     from cattus_amd.evaluator import HipEvaluator
 
-    threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
+    # search threads: the CPU share of this rank minus room for the two evaluation threads, the HIP runtime's
+    # threads and the main thread (15 search threads on a 16-CPU share starved them: 261 k vs 337 k node-evals/s)
+    threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 4)
     with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
         cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
                              first_game=rank, game_stride=world, seed=1, max_game_plies=max_game_plies,
@@ -442,7 +444,7 @@ def main():
     if headline and args.selfplay_seconds > 0:
         from cattus_amd import selfplay as sp
 
-        threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 1)
+        threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 4)
         # BASELINE config 3 as written: 800 sims/move, batch 256; 1024 concurrent games (two batches in flight
         # and two more ready to go); every game is cut after `plies` plies so that the leg fits its time budget (a whole
         # 800-sim game of ~290 plies costs ~170 k evaluations, 1024 of them ~9 minutes of GPU time)

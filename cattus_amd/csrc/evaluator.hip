@@ -226,6 +226,7 @@ struct cattus_eval {
     // (tower64_lds_kernel; CATTUS_TOWER64=0 selects the per-layer launches, for A/B runs and the equality test)
     bool tower64 = false;
     DevBuf t64_layers;
+    bool pack_separately = false;  // CATTUS_FUSED_STEM=0: plane pack as its own launch in front of the stem (A/B, tests)
     int device = 0;
 
     ConvLayer stem;
@@ -459,9 +460,13 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             if (const char* force = getenv("CATTUS_T64_CH")) ch = atoi(force) == 1 ? 1 : 2;  // A/B runs
             launch_tower64(ta, rows, ch, st, s0, s1);
         } else {
-            launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
+            // the stem conv expands the planes itself when they fit one 128-byte chunk (every game here); else K0 first
+            const bool fused_stem = d.planes <= 32 && e->cpad0 == (uint32_t)act_kc(e->act) && !e->pack_separately;
+            const StemInput stem_in{d_planes, n, d.planes, w64};
+            if (!fused_stem) launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
             hipEvent_t s0 = ev(false), s1 = ev(true);
-            launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1);
+            launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
+                                fused_stem ? &stem_in : nullptr);
             for (uint32_t i = 0; i < d.blocks; i++) {
                 s0 = ev(false), s1 = ev(true);
                 launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1);
@@ -688,6 +693,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if (cfg->device < 0 || cfg->device >= ndev) return fail(CATTUS_E_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
     const char* wait_mode = getenv("CATTUS_HIP_WAIT");
+    const char* fused_stem_env = getenv("CATTUS_FUSED_STEM");
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
     if (!e) return fail(CATTUS_E_NOMEM, "out of memory");
@@ -696,6 +702,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if (e->cfg.flush_us == 0) e->cfg.flush_us = 200;
     e->device = cfg->device;
     e->wait_spin = !(wait_mode && strcmp(wait_mode, "block") == 0);
+    e->pack_separately = fused_stem_env && fused_stem_env[0] == '0';
     e->hw = d.board * d.board;
     // The MFMA tower covers every board up to 11x11 and any filter count (channels are padded to 64 with zeros);
     // the two 1x1 head convs share one 32-row MFMA tile.  Wider heads take the generic f32 path (one thread

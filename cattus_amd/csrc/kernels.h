@@ -29,9 +29,15 @@ void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C
 // in [bpad][slots][cin], w [9][cout][cin], bias [cout] f32, res/out [bpad][slots][cout], slots = tower_slots(S).
 // Requires bpad * slots % 256 == 0, cin % kc == 0, cout % 64 == 0, S <= 11.
 // ev_start / ev_stop (optional): events stamped with the kernel's own begin / end time.
+// stem (optional): the layer reads the leaves' bitboard planes instead of `in` (K0 fused into the stem conv: the
+// loader waves expand the planes straight into LDS).  Requires C <= 32 planes and cin == one 128-byte row.
+struct StemInput {
+    const uint64_t* planes;  // [n][C][w64]
+    uint32_t n, C, w64;
+};
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
-                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const StemInput* stem = nullptr);
 
 // ---- K1 resident: whole tower of a network with <= 64 (padded) filters in one launch, bf16 (see kernels.hip) ----
 struct Tower64Layer {

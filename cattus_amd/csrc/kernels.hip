@@ -236,11 +236,23 @@ constexpr int NLOAD = CATTUS_NLOAD;
 constexpr int WPL = 24 / NLOAD;  // weight pieces per loader wave and step
 constexpr int APL = 16 / NLOAD;  // activation pieces per loader wave and half-chunk
 
+// Stem input of the STEM variant: the leaves' bitboard planes (K0 fused: the loader waves expand them into the
+// activation chunk in LDS instead of fetching a packed tensor).  Empty for the other layers, so that their
+// kernel arguments stay within the 16 preloaded dwords.
+template <bool STEM>
+struct StemPlanes {};
+template <>
+struct StemPlanes<true> {
+    const uint64_t* planes;  // [n][C][w64]
+    uint32_t n, C, w64;
+};
+
 // BIG: 128 pixel slots per board (two consumer waves per board).
-template <typename T, bool HAS_RES, bool BIG>
+// STEM: the layer's input is the bitboard planes (C <= 32 planes, one 128-byte chunk): `in` is not read.
+template <typename T, bool HAS_RES, bool BIG, bool STEM = false>
 __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S) {
+                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S, StemPlanes<STEM> sp) {
     constexpr int KC = 128 / (int)sizeof(T);
     typedef typename Mfma<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -306,10 +318,43 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             for (int i = 0; i < APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
         };
 
-        issue_a(0, 0);
-        issue_a(0, 1);
-        issue_w(0);
-        issue_w(1);
+        if constexpr (STEM) {
+            // K0 fused: this thread expands pixel row (lw * 64 + lane) of the workgroup's 256 rows.  All plane words
+            // of its board first (one round trip), the first weight slabs behind them, then the row: channel c of
+            // the row is 1.0 where plane c has the pixel's bit; channel slot s lands in LDS slot s ^ swizzle(row),
+            // where the LDS-DMA path would have put it.
+            constexpr int VEC = 16 / (int)sizeof(T);   // channels per 16-byte slot
+            constexpr int MAXC = 32;
+            const int row = lw * 64 + lane;
+            const uint32_t grow = (uint32_t)(row0 + row), slots = BIG ? 128u : 64u;
+            const uint32_t board = grow / slots, px = grow % slots;
+            const bool live = board < sp.n && (int)px < S * S;
+            typedef const __attribute__((address_space(1))) uint64_t* gu64p;
+            const gu64p pl = (gu64p)(sp.planes + (size_t)(live ? board : 0) * sp.C * sp.w64 + (live ? (px >> 6) : 0));
+            uint64_t words[MAXC];
+#pragma unroll
+            for (int c = 0; c < MAXC; c++) words[c] = (live && (uint32_t)c < sp.C) ? pl[(size_t)c * sp.w64] : 0ull;
+            issue_w(0);
+            issue_w(1);
+            char* dstrow = smem + V2_LDS_ACT + row * 128;
+            const int swz = (row >> 1) & 7;
+#pragma unroll
+            for (int sl = 0; sl < 8; sl++) {
+                T vals[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; i++) {
+                    const int c = sl * VEC + i;
+                    vals[i] = (c < MAXC && ((words[c < MAXC ? c : 0] >> (px & 63)) & 1ull)) ? (T)1.0f : (T)0.0f;
+                }
+                *reinterpret_cast<f32x4*>(dstrow + ((sl ^ swz) << 4)) = *reinterpret_cast<f32x4*>(vals);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are written before the first barrier
+        } else {
+            issue_a(0, 0);
+            issue_a(0, 1);
+            issue_w(0);
+            issue_w(1);
+        }
         int pending = WPL;  // loads issued after the data of the upcoming step
         for (int t = 0; t < T_total; t++) {
 #ifdef CATTUS_STAMPS
@@ -552,22 +597,36 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st, hipEvent_t ev_start,
-                         hipEvent_t ev_stop) {
+                         hipEvent_t ev_stop, const StemInput* stem) {
     const uint32_t slots = tower_slots(S);
     const dim3 grid((bpad * slots / ROWS_PER_WG) * (cout / COUT_PER_WG));
 #define CATTUS_LAUNCH_CONV2(T, R, BIG)                                                                    \
     do {                                                                                                  \
         static std::atomic<uint64_t> attr_set{0};                                                         \
         if (first_use_on_device(attr_set)) {                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R, BIG>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R, BIG, false>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
         }                                                                                                 \
-        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                              (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S); \
+        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                              (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{}); \
+    } while (0)
+#define CATTUS_LAUNCH_STEM(T, BIG)                                                                        \
+    do {                                                                                                  \
+        static std::atomic<uint64_t> attr_set{0};                                                         \
+        if (first_use_on_device(attr_set)) {                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, BIG, true>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
+        }                                                                                                 \
+        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                              (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
+                              StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64});               \
     } while (0)
 #define CATTUS_LAUNCH_CONV2_T(T)                             \
     do {                                                     \
-        if (slots == 128) {                                  \
+        if (stem) {                                          \
+            if (slots == 128) CATTUS_LAUNCH_STEM(T, true);   \
+            else CATTUS_LAUNCH_STEM(T, false);               \
+        } else if (slots == 128) {                           \
             if (res) CATTUS_LAUNCH_CONV2(T, true, true);     \
             else CATTUS_LAUNCH_CONV2(T, false, true);        \
         } else {                                             \
@@ -578,6 +637,7 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
     if (act == Act::BF16) CATTUS_LAUNCH_CONV2_T(__bf16);
     else CATTUS_LAUNCH_CONV2_T(float);
 #undef CATTUS_LAUNCH_CONV2_T
+#undef CATTUS_LAUNCH_STEM
 #undef CATTUS_LAUNCH_CONV2
 }
 

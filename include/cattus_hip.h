@@ -99,7 +99,9 @@ int cattus_hip_eval_device(cattus_eval* e, const uint64_t* d_planes, uint32_t n,
  * cattus_hip_eval_device uses lane 0.  This variant names the lane: work enqueued on different lanes
  * and different streams may overlap on the device (the tail of one batch's kernels with the head of
  * the other's).  Two calls on the same lane must be ordered by the caller (same stream or events). */
+#ifndef CATTUS_HIP_LANES
 #define CATTUS_HIP_LANES 2
+#endif
 int cattus_hip_eval_device_lane(cattus_eval* e, uint32_t lane, const uint64_t* d_planes, uint32_t n,
                                 float* d_policy, float* d_value, void* stream);
 /* The lane's own non-blocking stream (the one cattus_hip_eval uses for that lane), for callers of the

@@ -138,6 +138,24 @@ def test_resident_tower_equals_per_layer_launches(game, desc, words, n, monkeypa
         assert ev.time_tower(min(n, 8), 1)[1] == 1  # one tower launch per forward
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["chess_20x256", "hex11_2x8"])
+def test_fused_stem_equals_separate_plane_pack(name, dtype, monkeypatch):
+    """The stem conv of the per-layer path expands the bitboard planes in its loader waves (K0 fused); with
+    CATTUS_FUSED_STEM=0 the planes go through pack_planes_nhwc_kernel first.  Same bits either way."""
+    d, blob, z = blob_for(name)
+    planes = np.concatenate([z["planes"]] * 2)[: len(z["planes"]) + 3]
+    words = _plane_words(planes)
+    monkeypatch.setenv("CATTUS_TOWER64", "0")  # the per-layer path also for the small net
+    monkeypatch.setenv("CATTUS_FUSED_STEM", "0")
+    with HipEvaluator(blob, batch_size=len(planes), plane_words=words, dtype=dtype) as ev:
+        want_p, want_v = ev.eval(planes)
+    monkeypatch.delenv("CATTUS_FUSED_STEM")
+    with HipEvaluator(blob, batch_size=len(planes) + 2, plane_words=words, dtype=dtype) as ev:
+        got_p, got_v = ev.eval(planes)
+    assert (got_p == want_p).all() and (got_v == want_v).all()
+
+
 def test_wide_heads_take_the_generic_path_and_refuse_bf16():
     d = NetDesc(**hex_game(5), blocks=1, filters=32, vhc=24, phc=24)  # 48 head channels > one 32-row MFMA tile
     blob = seeded_blob(d, 4)
