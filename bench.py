@@ -232,7 +232,7 @@ def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, ma
             import torch.distributed as dist
 
             t1 = time.perf_counter()
-            recs, _meta = cdist.pool_records(res["record_bytes"], res["record_meta"], device=dev)
+            recs, _meta = cdist.pool_records(res["record_bytes"], res["record_meta"], device=dev)  # dev: where the collectives run
             tot = cdist.reduce_counters(res, device=dev)
             torch.cuda.synchronize()
             pool_s = time.perf_counter() - t1
@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="chess20x256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, choices=[1, 2], default=1,
+    ap.add_argument("--lanes", type=int, choices=[1, 2], default=2,
                     help="2 = also time the K steps with two batches in flight (extra object; `value` stays single-stream)")
     ap.add_argument("--selfplay-seconds", type=float, default=40.0, help="time budget of the 800-sim self-play leg (0 = skip all self-play legs)")
     ap.add_argument("--selfplay-sims", type=int, default=800, help="simulations per move of the end-to-end leg (BASELINE config 3: 800)")
@@ -301,13 +301,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the leaf evaluator has no CPU path")
+    # Rehearsal of the N > 1 code path on a box with one GPU (never for a quoted number): BENCH_REHEARSAL=1 puts
+    # every rank on device 0 and runs the collectives over gloo on host tensors.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
     headline = args.workload == "chess20x256"
     want_pg = world > 1 or (headline and args.selfplay_seconds > 0)  # config 4's leg pools records over RCCL, also on one rank
     if want_pg:
-        if world > 1:
+        if rehearsal:
+            dist.init_process_group("gloo")
+        elif world > 1:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1,
@@ -319,6 +326,7 @@ def main():
     batch = len(planes)
     plane_words = planes.shape[2]
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev  # where the collectives' tensors live
     d_planes = torch.from_numpy(planes.view(np.int64)).to(dev)
     stream = torch.cuda.Stream(device=dev)  # everything timed runs on this stream (not the legacy default stream)
 
@@ -329,7 +337,7 @@ def main():
 
     def max_over_ranks(x):
         if world > 1:
-            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            t = torch.tensor([x], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return x
@@ -356,6 +364,15 @@ def main():
         # roofline of the dominant kernel (3x3 conv tower launch): event-stamped launch durations of the same
         # forward, taken right behind the timed region so that the device is in the same state as for `value`
         launch_us, launches = ev.time_tower(batch, 20) if rank == 0 else (0.0, 1)
+        # the same measurement over 400 steps (the driver times 20: 15 ms, inside the clock governor's settling time)
+        long_ms = None
+        if dtype == "bf16" and steps < 400:
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(400):
+                step()
+            sync_all()
+            long_ms = max_over_ranks(time.perf_counter() - t0) / 400 * 1e3
         elapsed2 = None
         if lanes == 2:
             # the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
@@ -382,7 +399,7 @@ def main():
             elapsed2 = max_over_ranks(time.perf_counter() - t0)
             assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
         ev.close()
-        return elapsed, launch_us, launches, elapsed2, "tower64_lds_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel"
+        return elapsed, launch_us, launches, elapsed2, "tower64_lds_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel", long_ms
 
     def roofline(dtype, launch_us, launches, kernel):
         flop_per_launch = d.conv_flops_per_position() * batch / launches
@@ -401,13 +418,13 @@ def main():
             "flop_per_launch": flop_per_launch,
         }
 
-    elapsed, launch_us, launches, elapsed2, kname = time_evaluator(args.dtype, args.steps, args.warmup, args.lanes)
+    elapsed, launch_us, launches, elapsed2, kname, long_ms = time_evaluator(args.dtype, args.steps, args.warmup, args.lanes)
     kname = kname or "conv3x3_mfma_v2_kernel"
 
     f32_out = None
     if args.dtype == "bf16" and not args.no_f32:
         steps32 = max(5, args.steps // 10)
-        e32, us32, l32, _, k32 = time_evaluator("f32", steps32, max(2, args.warmup // 10))
+        e32, us32, l32, _, k32, _ = time_evaluator("f32", steps32, max(2, args.warmup // 10))
         if rank == 0:
             f32_out = {
                 "value": world * batch * steps32 / e32,
@@ -451,8 +468,8 @@ def main():
         capacity = min(330e3, threads * 60e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
         plies = int(max(4, min(64, args.selfplay_seconds * capacity / (1024 * 0.75 * args.selfplay_sims))))
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=1024, slots=1024, sims=args.selfplay_sims, max_game_plies=plies,
-                           keep_records=False, pool=False, torch=torch, dev=dev)
-        sp_out = reduce_leg(leg, torch, dev, world)
+                           keep_records=False, pool=False, torch=torch, dev=cdev)
+        sp_out = reduce_leg(leg, torch, cdev, world)
         sp_out.update(max_game_plies=plies, settings=SELFPLAY_SETTINGS_TEXT,
                       note="bounded sample: every game is adjudicated after max_game_plies plies; games_per_hour_estimate = plies_per_sec "
                            "* 3600 / (plies per whole game measured in selfplay_full_games)")
@@ -460,15 +477,15 @@ def main():
         full_sims = 64
         full_games = int(min(1024, max(64, 25.0 * capacity / (190.0 * full_sims)))) // 2 * 2
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=full_games, slots=full_games, sims=full_sims, max_game_plies=0,
-                           keep_records=False, pool=False, torch=torch, dev=dev)
-        sp_full = reduce_leg(leg, torch, dev, world)
+                           keep_records=False, pool=False, torch=torch, dev=cdev)
+        sp_full = reduce_leg(leg, torch, cdev, world)
         sp_full.update(games_per_hour=sp_full["games"] * 3600.0 / sp_full["seconds"], settings=SELFPLAY_SETTINGS_TEXT)
         sp_out["games_per_hour_estimate"] = sp_out["plies_per_sec"] * 3600.0 / max(1.0, sp_full["plies_per_game"])
         # BASELINE config 4's shape: 64 concurrent games per GPU (sequential search: at most 64 leaves per batch), records
         # kept and pooled over RCCL (all-gather) with the counters all-reduced, all inside the timed region
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=64, slots=64, sims=args.selfplay_sims, max_game_plies=6,
-                           keep_records=True, pool=True, torch=torch, dev=dev)
-        sp_c4 = reduce_leg(leg, torch, dev, world)
+                           keep_records=True, pool=True, torch=torch, dev=cdev)
+        sp_c4 = reduce_leg(leg, torch, cdev, world)
         sp_c4.update(max_game_plies=6, pool_seconds=leg["pool_seconds"], pooled=leg["pooled"], settings=SELFPLAY_SETTINGS_TEXT,
                      note="64 games per GPU, records all-gathered and counters all-reduced through torch.distributed 'nccl' (= RCCL) inside "
                           "the timed region; one leaf per tree in flight, so a batch holds at most 64 leaves")
@@ -506,6 +523,8 @@ def main():
             from cattus_amd import evaluator as ev_mod
 
             out["roofline_plane_pack"] = pack_roofline(torch, ev_mod.load_library(), dev, stream)
+        if long_ms is not None:
+            out["same_over_400_steps"] = {"value": world * batch / (long_ms * 1e-3), "ms_per_step": long_ms}
         if elapsed2 is not None:
             out["two_batches_in_flight"] = {
                 "value": batch * world * args.steps / elapsed2,
