@@ -292,6 +292,7 @@ def main():
     ap.add_argument("--selfplay-sims", type=int, default=800, help="simulations per move of the end-to-end leg (BASELINE config 3: 800)")
     ap.add_argument("--agreement-plies", type=int, default=4, help="searched plies per game of the bf16-vs-f32 search agreement leg (0 = skip)")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 (reference precision) object")
+    ap.add_argument("--no-long-run", action="store_true", help="skip the extra 400-step measurement")
     args = ap.parse_args()
 
     import torch
@@ -366,7 +367,7 @@ def main():
         launch_us, launches = ev.time_tower(batch, 20) if rank == 0 else (0.0, 1)
         # the same measurement over 400 steps (the driver times 20: 15 ms, inside the clock governor's settling time)
         long_ms = None
-        if dtype == "bf16" and steps < 400:
+        if dtype == "bf16" and steps < 400 and not args.no_long_run:
             sync_all()
             t0 = time.perf_counter()
             for _ in range(400):
