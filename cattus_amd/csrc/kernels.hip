@@ -1088,37 +1088,68 @@ struct HeadEpi {
     uint32_t hw, vhc, ocn, hvs, kvp, M, slots;
 };
 
+// A block = 4 waves = a 32 (i) x 128 (j) strip: wave w owns j tile tj0 + w.  The operands go through LDS in chunks of
+// 256 bytes per row, fetched with whole-line loads (16 lanes per row; a fragment read straight from memory touches 32
+// lines per instruction and uses a quarter of each -- the heads were bound by that, not by bytes) and double-buffered
+// in registers, so a chunk's round trip to L2 hides under the previous chunk's MFMAs.  The MFMA order over k is
+// unchanged, so results are bit for bit those of the direct-load version.
+constexpr int HG_ROWB = 256;                    // operand bytes per row and chunk: 128 bf16 / 64 f32 = 8 MFMA stages
+constexpr int HG_PITCH = HG_ROWB + 16;          // LDS row pitch: ds_read_b128 down a column of rows is conflict-free
+constexpr int HG_LDS = (32 + 128) * HG_PITCH;   // P rows 0..31, Q rows 32..159
+constexpr int HG_PIECES = (32 + 128) * (HG_ROWB / 16) / 256;  // 16-byte pieces per thread and chunk (10)
+
 template <typename T, int EPI>
 __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t ldp, uint32_t I, const T* __restrict__ Q,
                                                uint32_t ldq, uint32_t J, uint32_t K, const HeadEpi& ep, uint32_t bx,
-                                               uint32_t by, float* stage = nullptr) {
+                                               uint32_t by, char* lds, float* stage = nullptr) {
     typedef typename Mfma<T>::frag frag;
-    constexpr uint32_t KSTEP = 32 / sizeof(T);  // k per MFMA stage: 16 (bf16) or 8 (f32)
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr uint32_t KSTEP = 32 / sizeof(T);       // k per MFMA stage: 16 (bf16) or 8 (f32)
+    constexpr uint32_t KCH = HG_ROWB / sizeof(T);    // k per chunk
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
-    const uint32_t i0 = by * 32, j0 = (bx * 4 + wave) * 32;
-    if (j0 >= J) return;
-    const uint32_t pi = min(i0 + r, I - 1), qj = min(j0 + r, J - 1);
-    const T* pp = P + (size_t)pi * ldp + h * (KSTEP / 2);
-    const T* qp = Q + (size_t)qj * ldq + h * (KSTEP / 2);
+    const uint32_t i0 = by * 32, jb0 = bx * 128, j0 = jb0 + wave * 32;
+    const bool active = j0 < J;  // a wave without a tile still helps with the staging
+    // this thread's pieces: piece q = tid + 256 t -> LDS row q >> 4 (P rows first), 16-byte column q & 15
+    const char* src[HG_PIECES];
+    uint32_t dst[HG_PIECES], colb[HG_PIECES];
+#pragma unroll
+    for (int t = 0; t < HG_PIECES; t++) {
+        const uint32_t q = tid + 256 * t, row = q >> 4;
+        colb[t] = (q & 15) * 16;
+        src[t] = row < 32 ? reinterpret_cast<const char*>(P + (size_t)min(i0 + row, I - 1) * ldp)
+                          : reinterpret_cast<const char*>(Q + (size_t)min(jb0 + row - 32, J - 1) * ldq);
+        dst[t] = row * HG_PITCH + colb[t];
+    }
+    const uint32_t kbytes = K * sizeof(T);
+    f32x4 pre[HG_PIECES];
+    auto fetch = [&](uint32_t c) {
+#pragma unroll
+        for (int t = 0; t < HG_PIECES; t++) {
+            const uint32_t off = c * HG_ROWB + colb[t];
+            pre[t] = off < kbytes ? *reinterpret_cast<const f32x4*>(src[t] + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.0f;
-    // The operands come straight from L2: the loop is a chain of load round trips, so keep many loads in
-    // flight (16 stages = 32 x 16 B per lane) rather than few; the MFMA order over k is unchanged.
-    constexpr uint32_t DEPTH = 16;
-    for (uint32_t k = 0; k < K; k += DEPTH * KSTEP) {
-        frag a[DEPTH], b[DEPTH];
+    const uint32_t nchunks = (K + KCH - 1) / KCH;
+    const char* arow = lds + r * HG_PITCH + h * 16;
+    const char* brow = lds + (32 + wave * 32 + r) * HG_PITCH + h * 16;
+    fetch(0);
+    for (uint32_t c = 0; c < nchunks; c++) {
 #pragma unroll
-        for (uint32_t u = 0; u < DEPTH; u++)
-            if (k + u * KSTEP < K) {
-                a[u] = *reinterpret_cast<const frag*>(pp + k + u * KSTEP);
-                b[u] = *reinterpret_cast<const frag*>(qp + k + u * KSTEP);
-            }
+        for (int t = 0; t < HG_PIECES; t++) *reinterpret_cast<f32x4*>(lds + dst[t]) = pre[t];
+        __syncthreads();
+        if (c + 1 < nchunks) fetch(c + 1);
+        if (active) {
 #pragma unroll
-        for (uint32_t u = 0; u < DEPTH; u++)
-            if (k + u * KSTEP < K) Mfma<T>::mac(a[u], b[u], acc);
+            for (uint32_t u = 0; u < KCH / KSTEP; u++)
+                if (c * KCH + u * KSTEP < K)
+                    Mfma<T>::mac(*reinterpret_cast<const frag*>(arow + u * 32), *reinterpret_cast<const frag*>(brow + u * 32), acc);
+        }
+        __syncthreads();
     }
+    if (!active) return;
     const uint32_t j = j0 + r;
     if (j >= J) return;
 #pragma unroll
@@ -1149,7 +1180,8 @@ template <typename T, int EPI>
 __global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P, uint32_t ldp, uint32_t I,
                                                         const T* __restrict__ Q, uint32_t ldq, uint32_t J, uint32_t K,
                                                         HeadEpi ep) {
-    head_gemm_tile<T, EPI>(P, ldp, I, Q, ldq, J, K, ep, blockIdx.x, blockIdx.y);
+    __shared__ __attribute__((aligned(16))) char hg_lds[HG_LDS];
+    head_gemm_tile<T, EPI>(P, ldp, I, Q, ldq, J, K, ep, blockIdx.x, blockIdx.y, hg_lds);
 }
 
 // Value FC1 and policy FC read the same head activations and do not depend on each other: one launch,
@@ -1164,11 +1196,12 @@ struct HeadFcPair {
 __device__ __forceinline__ float tanh_exact(float x);
 template <typename T>
 __global__ void __launch_bounds__(256) head_fc_pair_kernel(HeadFcPair a) {
+    __shared__ __attribute__((aligned(16))) char hg_lds[HG_LDS];
     if (blockIdx.x < a.fc1_blocks) {
         // The block's four waves hold all 128 hidden units of 32 leaves: stage them in LDS and finish the
         // value head here (FC2 + tanh, the fmaf chain of value_fc2_tanh_kernel), saving a launch.
         __shared__ float h1s[32 * 129];
-        head_gemm_tile<T, EPI_FC1>((const T*)a.p1, a.ldp, a.I, (const T*)a.q1, a.ldq1, a.J1, a.K1, a.ep1, blockIdx.x, blockIdx.y, h1s);
+        head_gemm_tile<T, EPI_FC1>((const T*)a.p1, a.ldp, a.I, (const T*)a.q1, a.ldq1, a.J1, a.K1, a.ep1, blockIdx.x, blockIdx.y, hg_lds, h1s);
         __syncthreads();
         const uint32_t leaf = blockIdx.y * 32 + threadIdx.x;
         if (threadIdx.x < 32 && leaf < a.I) {
@@ -1181,7 +1214,7 @@ __global__ void __launch_bounds__(256) head_fc_pair_kernel(HeadFcPair a) {
         }
     } else
         head_gemm_tile<T, EPI_POLICY>((const T*)a.p2, a.ldp, a.I, (const T*)a.q2, a.ldq2, a.J2, a.K2, a.ep2,
-                                      blockIdx.x - a.fc1_blocks, blockIdx.y);
+                                      blockIdx.x - a.fc1_blocks, blockIdx.y, hg_lds);
 }
 
 template <int EPI>
