@@ -1,9 +1,12 @@
 // gfx950 (MI355X / CDNA4) kernels of the Cattus leaf evaluator.
 //
-//   K0  pack_planes_nhwc / planes_to_tensor_nchw   bitboards -> tensors      (HBM-bound)
-//   K1  conv3x3_mfma<T, RES>                       3x3 conv + folded BN (+skip) + ReLU (MFMA-bound)
-//   K1g conv3x3_generic                            same arithmetic, any shape, SIMT f32
-//   K3  head_conv1x1, K4 value_fc1 / value_fc2_tanh, K5 policy_fc
+//   K0  planes_to_tensor_nchw[64] / pack_planes_nhwc    bitboards -> tensors (HBM-bound); inside the forward pass the
+//                                                       planes are expanded straight into LDS by K1 / K1r instead
+//   K1  conv3x3_mfma_v2<T, HAS_RES, BIG, STEM>          3x3 conv + folded BN (+skip) + ReLU, one launch per layer (MFMA-bound)
+//   K1r tower64_lds<CH, BIG>                            whole tower of a <= 64-filter bf16 network in one launch, activations in LDS
+//   K1g conv3x3_generic                                 same arithmetic, any shape, SIMT f32 (checker; wide heads)
+//   K3  head_gemm<HEADCONV>, K4 + K5 head_fc_pair       1x1 head convs; value FC1 + FC2 + tanh and policy FC (MFMA)
+//       head_conv1x1, value_fc1, value_fc2_tanh, policy_fc   the same on the generic path (SIMT f32)
 //
 // Arithmetic the kernels reproduce: ConvNetV1.forward in eval mode
 // (reference: training/cattus_train/net_utils.py:4-89) on the tensor planes_to_tensor builds
