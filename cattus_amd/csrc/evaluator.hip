@@ -693,6 +693,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if (cfg->device < 0 || cfg->device >= ndev) return fail(CATTUS_E_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
     const char* wait_mode = getenv("CATTUS_HIP_WAIT");
+    set_conv_cb(getenv("CATTUS_CONV_CB") ? atoi(getenv("CATTUS_CONV_CB")) : 0);
     const char* fused_stem_env = getenv("CATTUS_FUSED_STEM");
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);

@@ -39,6 +39,9 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const StemInput* stem = nullptr);
 
+// Forces the conv kernel's tile (1: 256 rows x 32 couts, 2: 256 rows x 64 couts; 0: chosen by grid size).
+void set_conv_cb(int v);
+
 // ---- K1 resident: whole tower of a network with <= 64 (padded) filters in one launch, bf16 (see kernels.hip) ----
 struct Tower64Layer {
     const void* w;      // [9][64][64] bf16 (stem: input channels padded to 64)

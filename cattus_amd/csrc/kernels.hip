@@ -252,11 +252,17 @@ struct StemPlanes<true> {
 
 // BIG: 128 pixel slots per board (two consumer waves per board).
 // STEM: the layer's input is the bitboard planes (C <= 32 planes, one 128-byte chunk): `in` is not read.
-template <typename T, bool HAS_RES, bool BIG, bool STEM = false>
+// CB: 32-cout blocks per workgroup.  2 = the 256 rows x 64 couts tile described above.  1 = 256 rows x 32 couts
+//     (consumer wave: 1 x 2 tiles): twice the workgroups for the same layer, used while the full-size grid would
+//     leave more than half of the CUs empty (batches of <= 128 leaves on a 256-filter net).  Same MFMA shape and
+//     k order per output element, so the result does not depend on which of the two ran.
+template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2>
 __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                            const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S, StemPlanes<STEM> sp) {
     constexpr int KC = 128 / (int)sizeof(T);
+    constexpr int CPW = 32 * CB;          // output channels of this workgroup
+    constexpr int WPLC = WPL * CB / 2;    // weight pieces per loader wave and step
     typedef typename Mfma<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -268,10 +274,10 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     STAMP(0);
     STAMP_RT(5);
 
-    const int nblk = gridDim.x, ncb = cout / COUT_PER_WG;
+    const int nblk = gridDim.x, ncb = cout / CPW;
     int logical = blockIdx.x;
     if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int cout0 = (logical % ncb) * COUT_PER_WG;
+    const int cout0 = (logical % ncb) * CPW;
     const int row0 = (logical / ncb) * ROWS_PER_WG;  // first tower row (board * slots + pixel slot) of this workgroup
 
     if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -285,15 +291,15 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         // ================================ loader waves ================================
         const int lw = wave - 4;
         const int prow = lane >> 3, pslot = lane & 7;
-        uint32_t off_w[WPL], off_a[2][APL];
-        int dst_w[WPL], dst_a[2][APL];
+        uint32_t off_w[WPLC], off_a[2][APL];
+        int dst_w[WPLC], dst_a[2][APL];
 #pragma unroll
-        for (int i = 0; i < WPL; i++) {
-            const int pid = lw * WPL + i;               // 0..23: tap_i = pid/8, 8 rows each
-            const int tap_i = pid >> 3, row = (pid & 7) * 8 + prow;
+        for (int i = 0; i < WPLC; i++) {
+            const int pid = lw * WPLC + i;              // 0..12*CB-1: tap_i = pid / (4*CB), 8 cout rows each
+            const int tap_i = pid / (4 * CB), within = pid - tap_i * (4 * CB), row = within * 8 + prow;
             const int c = pslot ^ ((row >> 1) & 7);
             off_w[i] = ((uint32_t)(tap_i * cout + row)) * row_bytes + c * 16;
-            dst_w[i] = pid * 1024;
+            dst_w[i] = tap_i * 8192 + within * 1024;    // a tap's rows start 8 KiB apart whatever CB is
         }
 #pragma unroll
         for (int g = 0; g < 2; g++)
@@ -312,7 +318,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)ch * 128;
             char* dst = smem + V2_LDS_W + (t % 3) * V2_SLAB;
 #pragma unroll
-            for (int i = 0; i < WPL; i++) glds16(src + off_w[i], dst + dst_w[i]);
+            for (int i = 0; i < WPLC; i++) glds16(src + off_w[i], dst + dst_w[i]);
         };
         auto issue_a = [&](int ch, int g) {  // half g of activation chunk ch -> buffer ch & 1
             const char* src = abase0 + (size_t)ch * 128;
@@ -358,13 +364,13 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             issue_w(0);
             issue_w(1);
         }
-        int pending = WPL;  // loads issued after the data of the upcoming step
+        int pending = WPLC;  // loads issued after the data of the upcoming step
         for (int t = 0; t < T_total; t++) {
 #ifdef CATTUS_STAMPS
             {  // diagnostic build: time the wait for the data (slot 4) and the wait at the barrier (slot 7) apart
                 const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
-                if (pending == WPL + APL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPL + APL) : "memory");
-                else if (pending == WPL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPL) : "memory");
+                if (pending == WPLC + APL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPLC + APL) : "memory");
+                else if (pending == WPLC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPLC) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
                 asm volatile("s_barrier" ::: "memory");
@@ -372,8 +378,8 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 st_[7] += __builtin_amdgcn_s_memtime() - t1_;
             }
 #else
-            if (pending == WPL + APL) wait_vm_barrier<WPL + APL>();
-            else if (pending == WPL) wait_vm_barrier<WPL>();
+            if (pending == WPLC + APL) wait_vm_barrier<WPLC + APL>();
+            else if (pending == WPLC) wait_vm_barrier<WPLC>();
             else wait_vm_barrier<0>();
 #endif
             if (t == 0) STAMP(1);
@@ -381,7 +387,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             const int ch = t / 3, g = t - ch * 3;
             if (t + 2 < T_total) {
                 issue_w(t + 2);
-                pending += WPL;
+                pending += WPLC;
             }
             if (g < 2 && ch + 1 < nch) {
                 issue_a(ch + 1, g);
@@ -414,17 +420,17 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         pvalid[pb] = p < S * S;
     }
     // weight fragment address per (k-slice, cout block): loop-invariant; ring slot and tap are immediates
-    int aaddr[4][2];
+    int aaddr[4][CB];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
+    for (int cb = 0; cb < CB; cb++) {
         const int row = cb * 32 + r;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) aaddr[ks][cb] = V2_LDS_W + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[CB][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < CB; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -433,25 +439,28 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     // Epilogue operands that depend on nothing computed here are requested now, so their latency hides
     // under the main loop: the folded-BN bias of this lane's 8 cout quads, and (2-byte activations only,
     // for register budget) the skip-connection rows in the epilogue's (pixel row, 8 couts) layout.
-    f32x4 biasv[2][4];
+    f32x4 biasv[CB][4];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < CB; cb++)
 #pragma unroll
         for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
+    // epilogue store layout: a pixel row of the tile is CPW couts = LPR lanes x 8 couts; 64 / LPR rows per trip
+    constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = 64 / RPT;
+    const int prow = lane / LPR, cg = lane % LPR;
     constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2;
-    T resv[8][8];
+    T resv[EIT][8];
     if (RES_EARLY) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const size_t off = ((size_t)row0 + wave * 64 + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
+        for (int i = 0; i < EIT; i++) {
+            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * (size_t)cout + cout0 + cg * 8;
             *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
         }
     }
 
-    // A step is 12 fragment stages (3 taps x 4 k-slices); each stage = 2 weight + 2 activation
-    // fragments feeding 4 MFMAs.  Fragments are read two stages ahead of the MFMAs that consume them
-    // (3-deep register ring) so the LDS latency hides under the 8 MFMAs in between.
-    constexpr int AHEAD = 2, RING = 3;
+    // A step is 12 fragment stages (3 taps x 4 k-slices); each stage = CB weight + 2 activation
+    // fragments feeding 2 CB MFMAs.  Fragments are read AHEAD stages before the MFMAs that consume them
+    // (register ring) so the LDS latency hides under the MFMAs in between.
+    constexpr int AHEAD = CB == 2 ? 2 : 3, RING = AHEAD + 1;
     int opaque = 0;
     for (int ch = 0; ch < nch; ch++) {
         const int abase = V2_LDS_ACT + (ch & 1) * 32768 + board_lds;
@@ -482,28 +491,28 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
                 }
-            frag fa[RING][2], fb[RING][2];
-            auto load_stage = [&](int i, frag (&a)[2], frag (&b)[2]) {
+            frag fa[RING][CB], fb[RING][2];
+            auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[2]) {
                 const int dxi = i >> 2, ks = i & 3;
 #pragma unroll
-                for (int cb = 0; cb < 2; cb++)
+                for (int cb = 0; cb < CB; cb++)
                     a[cb] = *reinterpret_cast<const frag*>(smem + aaddr[ks][cb] + (wslab + dxi * 8192));
 #pragma unroll
                 for (int pb = 0; pb < 2; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][ks]);
             };
 #pragma unroll
             for (int i = 0; i < AHEAD; i++) load_stage(i, fa[i % RING], fb[i % RING]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 * AHEAD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (CB + 2) * AHEAD, 0);
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 if (i + AHEAD < 12) load_stage(i + AHEAD, fa[(i + AHEAD) % RING], fb[(i + AHEAD) % RING]);
 #pragma unroll
-                for (int cb = 0; cb < 2; cb++)
+                for (int cb = 0; cb < CB; cb++)
 #pragma unroll
                     for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
                 // pin the issue order: this stage's look-ahead reads, then its MFMAs
-                if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
+                if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, CB + 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CB * 2 * (sizeof(T) == 2 ? 1 : 4), 0);
             }
         }
     }
@@ -526,8 +535,8 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         // skip-connection rows in the final (pixel row, 8 couts) layout, requested before the transpose
         if (HAS_RES && !RES_EARLY) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const size_t off = (wrow0 + i * 8 + (lane >> 3)) * (size_t)cout + cout0 + (lane & 7) * 8;
+            for (int i = 0; i < EIT; i++) {
+                const size_t off = (wrow0 + i * RPT + prow) * (size_t)cout + cout0 + cg * 8;
                 if (sizeof(T) == 2) {
                     *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
                 } else {
@@ -536,8 +545,11 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 }
             }
         }
+        // staged tile: CB = 2: f32 [px][64 couts] = 256-byte rows, px 0..31 at tile0, px 32..63 32768 bytes further;
+        //              CB = 1: f32 [px][32 couts] = 128-byte rows, all 64 at tile0
+        auto stage_row = [&](int px) { return CB == 2 ? tile0 + (px >> 5) * 32768 + (px & 31) * 256 : tile0 + px * 128; };
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++)
+        for (int cb = 0; cb < CB; cb++)
 #pragma unroll
             for (int pb = 0; pb < 2; pb++)
 #pragma unroll
@@ -547,15 +559,14 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 #pragma unroll
                     for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
                     const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
-                    *reinterpret_cast<f32x4*>(smem + tile0 + pb * 32768 + r * 256 + slot * 16) = v;
+                    *reinterpret_cast<f32x4*>(smem + stage_row(pb * 32 + r) + slot * 16) = v;
                 }
-        const int prow = lane >> 3, cg = lane & 7;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int px = i * 8 + prow, pb = px >> 5, rr = px & 31;
-            const char* rowp = smem + tile0 + pb * 32768 + rr * 256;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (rr & 7)) << 4));
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (rr & 7)) << 4));
+        for (int i = 0; i < EIT; i++) {
+            const int px = i * RPT + prow;
+            const char* rowp = smem + stage_row(px);
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (px & 7)) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (px & 7)) << 4));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const size_t off = (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
             if (HAS_RES) {
@@ -598,48 +609,61 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 }
 #endif
 
+int g_conv_cb = 0;  // 0: by grid size; 1 / 2: 32 / 64 couts per workgroup (CATTUS_CONV_CB, A/B runs and the equality test)
+void set_conv_cb(int v) { g_conv_cb = (v == 1 || v == 2) ? v : 0; }
+
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st, hipEvent_t ev_start,
                          hipEvent_t ev_stop, const StemInput* stem) {
     const uint32_t slots = tower_slots(S);
-    const dim3 grid((bpad * slots / ROWS_PER_WG) * (cout / COUT_PER_WG));
-#define CATTUS_LAUNCH_CONV2(T, R, BIG)                                                                    \
+    // 256 rows x 64 couts per workgroup; 256 rows x 32 couts while that grid would leave half of the CUs empty
+    const uint32_t full_grid = (bpad * slots / ROWS_PER_WG) * (cout / COUT_PER_WG);
+    int cb = full_grid <= 128 ? 1 : 2;
+    if (g_conv_cb) cb = g_conv_cb;
+    const dim3 grid(full_grid * (cb == 1 ? 2 : 1));
+#define CATTUS_LAUNCH_CONV2(T, R, BIG, CBV)                                                               \
     do {                                                                                                  \
         static std::atomic<uint64_t> attr_set{0};                                                         \
         if (first_use_on_device(attr_set)) {                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R, BIG, false>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
         }                                                                                                 \
-        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
                               (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{}); \
     } while (0)
-#define CATTUS_LAUNCH_STEM(T, BIG)                                                                        \
+#define CATTUS_LAUNCH_STEM(T, BIG, CBV)                                                                   \
     do {                                                                                                  \
         static std::atomic<uint64_t> attr_set{0};                                                         \
         if (first_use_on_device(attr_set)) {                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, BIG, true>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
         }                                                                                                 \
-        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
                               (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
                               StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64});               \
     } while (0)
-#define CATTUS_LAUNCH_CONV2_T(T)                             \
-    do {                                                     \
-        if (stem) {                                          \
-            if (slots == 128) CATTUS_LAUNCH_STEM(T, true);   \
-            else CATTUS_LAUNCH_STEM(T, false);               \
-        } else if (slots == 128) {                           \
-            if (res) CATTUS_LAUNCH_CONV2(T, true, true);     \
-            else CATTUS_LAUNCH_CONV2(T, false, true);        \
-        } else {                                             \
-            if (res) CATTUS_LAUNCH_CONV2(T, true, false);    \
-            else CATTUS_LAUNCH_CONV2(T, false, false);       \
-        }                                                    \
+#define CATTUS_LAUNCH_CONV2_CB(T, CBV)                            \
+    do {                                                          \
+        if (stem) {                                               \
+            if (slots == 128) CATTUS_LAUNCH_STEM(T, true, CBV);   \
+            else CATTUS_LAUNCH_STEM(T, false, CBV);               \
+        } else if (slots == 128) {                                \
+            if (res) CATTUS_LAUNCH_CONV2(T, true, true, CBV);     \
+            else CATTUS_LAUNCH_CONV2(T, false, true, CBV);        \
+        } else {                                                  \
+            if (res) CATTUS_LAUNCH_CONV2(T, true, false, CBV);    \
+            else CATTUS_LAUNCH_CONV2(T, false, false, CBV);       \
+        }                                                         \
+    } while (0)
+#define CATTUS_LAUNCH_CONV2_T(T)                  \
+    do {                                          \
+        if (cb == 1) CATTUS_LAUNCH_CONV2_CB(T, 1); \
+        else CATTUS_LAUNCH_CONV2_CB(T, 2);        \
     } while (0)
     if (act == Act::BF16) CATTUS_LAUNCH_CONV2_T(__bf16);
     else CATTUS_LAUNCH_CONV2_T(float);
 #undef CATTUS_LAUNCH_CONV2_T
+#undef CATTUS_LAUNCH_CONV2_CB
 #undef CATTUS_LAUNCH_STEM
 #undef CATTUS_LAUNCH_CONV2
 }

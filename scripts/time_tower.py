@@ -8,13 +8,18 @@ from cattus_amd.evaluator import HipEvaluator  # noqa: E402
 
 args = sys.argv[1:]
 warm = 20
+batch = None
+if args and args[0] == "--batch":  # time the tower on the first BATCH leaves of the workload
+    batch, args = int(args[1]), args[2:]
 if args and args[0] == "--warm":
     warm, args = int(args[1]), args[2:]
 for wl in args:
-    d, blob, planes = bench.make_workload(wl)
-    ev = HipEvaluator(blob, batch_size=len(planes), plane_words=planes.shape[2], dtype="bf16")
-    ev.time_tower(len(planes), warm)
-    us, launches = ev.time_tower(len(planes), 200)
+    d, blob, planes = bench.make_workload(wl.split(":")[0])
+    n = batch or len(planes)
+    dtype = "f32" if wl.endswith(":f32") else "bf16"
+    ev = HipEvaluator(blob, batch_size=len(planes), plane_words=planes.shape[2], dtype=dtype)
+    ev.time_tower(n, warm)
+    us, launches = ev.time_tower(n, 200 if dtype == "bf16" else 20)
     print(wl, "tower launch us:", round(us, 2), "x", launches, end="  |  ")
     ev.close()
 print()

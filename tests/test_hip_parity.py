@@ -156,6 +156,34 @@ def test_fused_stem_equals_separate_plane_pack(name, dtype, monkeypatch):
     assert (got_p == want_p).all() and (got_v == want_v).all()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("game,desc,words,n", [
+    ("chess", dict(**CHESS, blocks=3, filters=256, vhc=8, phc=8), 1, 70),
+    ("hex11", dict(**hex_game(11), blocks=2, filters=128, vhc=16, phc=16), 2, 21),
+])
+def test_half_cout_workgroups_equal_full_ones(game, desc, words, n, dtype, monkeypatch):
+    """Small batches run the conv layers on 256-row x 32-cout workgroups (twice as many) so that more of the
+    chip is busy; same MFMA shape and k order, so the bits do not depend on which tile ran."""
+    d = NetDesc(**desc)
+    blob = seeded_blob(d, 23)
+    rng = np.random.default_rng(11)
+    hw = d.board * d.board
+    planes = np.zeros((n, d.planes, words), dtype=np.uint64)
+    bits = rng.integers(0, 2, size=(n, d.planes, hw), dtype=np.uint64)
+    for i in range(hw):
+        planes[:, :, i >> 6] |= bits[:, :, i] << np.uint64(i & 63)
+    outs = []
+    for cb in ("2", "1"):
+        monkeypatch.setenv("CATTUS_CONV_CB", cb)
+        with HipEvaluator(blob, batch_size=n, plane_words=words, dtype=dtype) as ev:
+            outs.append(ev.eval(planes))
+    monkeypatch.delenv("CATTUS_CONV_CB")
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+    if dtype == "f32":
+        want_p, want_v = oracle.OracleNet(blob).forward(planes[:8])
+        assert (outs[1][0][:8] == want_p).all() and (outs[1][1][:8] == want_v).all()
+
+
 def test_wide_heads_take_the_generic_path_and_refuse_bf16():
     d = NetDesc(**hex_game(5), blocks=1, filters=32, vhc=24, phc=24)  # 48 head channels > one 32-row MFMA tile
     blob = seeded_blob(d, 4)
