@@ -352,6 +352,18 @@ def main():
         def step():
             ev.eval_device(d_planes.data_ptr(), batch, d_policy.data_ptr(), d_value.data_ptr(), stream.cuda_stream)
 
+        # The same measurement over 400 steps, FIRST: the driver times 20 steps behind 5 warm-up steps, i.e. 20 ms after
+        # the process touched the GPU for the first time, and the clock governor needs longer than that to settle (on
+        # one box: 322 k node-evals/s in that window, 359 k over the 400 steps that followed it).  With this run in
+        # front, the W warm-up steps and the K timed steps below see the device in its steady state.
+        long_ms = None
+        if dtype == "bf16" and steps < 400 and not args.no_long_run:
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(400):
+                step()
+            sync_all()
+            long_ms = max_over_ranks(time.perf_counter() - t0) / 400 * 1e3
         for _ in range(warmup):
             step()
         sync_all()
@@ -365,15 +377,6 @@ def main():
         # roofline of the dominant kernel (3x3 conv tower launch): event-stamped launch durations of the same
         # forward, taken right behind the timed region so that the device is in the same state as for `value`
         launch_us, launches = ev.time_tower(batch, 20) if rank == 0 else (0.0, 1)
-        # the same measurement over 400 steps (the driver times 20: 15 ms, inside the clock governor's settling time)
-        long_ms = None
-        if dtype == "bf16" and steps < 400 and not args.no_long_run:
-            sync_all()
-            t0 = time.perf_counter()
-            for _ in range(400):
-                step()
-            sync_all()
-            long_ms = max_over_ranks(time.perf_counter() - t0) / 400 * 1e3
         elapsed2 = None
         if lanes == 2:
             # the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
@@ -525,7 +528,8 @@ def main():
 
             out["roofline_plane_pack"] = pack_roofline(torch, ev_mod.load_library(), dev, stream)
         if long_ms is not None:
-            out["same_over_400_steps"] = {"value": world * batch / (long_ms * 1e-3), "ms_per_step": long_ms}
+            out["same_over_400_steps"] = {"value": world * batch / (long_ms * 1e-3), "ms_per_step": long_ms,
+                                          "note": "run before the W warm-up steps and the K timed steps of `value` (settles the clock governor)"}
         if elapsed2 is not None:
             out["two_batches_in_flight"] = {
                 "value": batch * world * args.steps / elapsed2,
