@@ -32,6 +32,9 @@ from pathlib import Path
 
 import numpy as np
 
+# kernel arguments in device memory (read by the HIP runtime when it initialises; cattus_amd/csrc/evaluator.hip)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 

@@ -28,6 +28,14 @@
 #include "../../include/cattus_hip.h"
 #include "kernels.h"
 
+// Kernel arguments in device memory.  By default the HIP runtime keeps the kernel-argument ring in host memory and the
+// command processor fetches every launch's arguments over the host link before the first wave starts: ~1.6 us per
+// launch, 8 % of a 41-launch forward pass (profiles/r02_experiments.txt).  The runtime reads the switch once, when it
+// initialises, so it is set when this library is loaded -- in a host where this library is the first HIP user (the
+// reference's self-play binary) that is early enough; a host that initialises HIP itself sets it in its environment
+// (bench.py and cattus_amd/__init__.py do).  An explicit setting in the environment wins.
+__attribute__((constructor)) static void cattus_hip_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+
 using namespace cattus;
 
 #define CATTUS_API extern "C" __attribute__((visibility("default")))
@@ -454,10 +462,15 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             ta.head_w = e->head_w.p, ta.head_b = e->head_b.as<float>(), ta.hv = L.hv.p;
             ta.hvs = e->kvp + e->kpp, ta.kvp = e->kvp, ta.vhc = d.vhc, ta.ocn = d.vhc + d.phc;
             const uint32_t rows = nb * e->slots;
-            // 256-row workgroups once they fill the chip, else twice as many 128-row ones
+            // 256-row workgroups once they fill the chip, else twice as many 128-row ones, else (64-slot boards) one
+            // board per workgroup while that still leaves no CU with two of them
             hipEvent_t s0 = ev(false), s1 = ev(true);
             int ch = rows / ROWS_PER_WG >= 256 ? 1 : 2;
-            if (const char* force = getenv("CATTUS_T64_CH")) ch = atoi(force) == 1 ? 1 : 2;  // A/B runs
+            if (ch == 2 && e->slots == 64 && rows / 64 <= 256) ch = 4;
+            if (const char* force = getenv("CATTUS_T64_CH")) {  // A/B runs
+                const int f = atoi(force);
+                ch = f == 1 ? 1 : (f == 4 && e->slots == 64) ? 4 : 2;
+            }
             launch_tower64(ta, rows, ch, st, s0, s1);
         } else {
             // the stem conv expands the planes itself when they fit one 128-byte chunk (every game here); else K0 first

@@ -198,7 +198,16 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 #define STAMP_FLUSH(wave)                                                          \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)                               \
         for (int q_ = 0; q_ < 8; q_++) g_stamps[(blockIdx.x * 16 + (wave)) * 8 + q_] = st_[q_]
+__device__ unsigned long long g_hstamps[256 * 4 * 8];
+#define HSTAMP_PARAM , unsigned long long* st_
+#define HSTAMP_PASS , st_
+#define HSTAMP_FLUSH                                                                                  \
+    if ((threadIdx.x & 63) == 0 && blockIdx.y * gridDim.x + blockIdx.x < 256)                          \
+        for (int q_ = 0; q_ < 8; q_++) g_hstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + q_] = st_[q_]
 #else
+#define HSTAMP_PARAM
+#define HSTAMP_PASS
+#define HSTAMP_FLUSH
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_RT(i)
@@ -607,6 +616,9 @@ static bool first_use_on_device(std::atomic<uint64_t>& mask) {
 extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(unsigned long long* out, size_t n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long));
 }
+extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_head_stamps(unsigned long long* out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hstamps), n * sizeof(unsigned long long));
+}
 #endif
 
 int g_conv_cb = 0;  // 0: by grid size; 1 / 2: 32 / 64 couts per workgroup (CATTUS_CONV_CB, A/B runs and the equality test)
@@ -686,6 +698,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 // CH = 1: 256 tower rows per workgroup, consumer wave w owns rows 64w..64w+63 x 64 couts (2x2 MFMA tiles).
 // CH = 2: 128 rows per workgroup (twice the workgroups: small batches), wave w owns row block w>>1 and the
 //         32 couts of half w&1 (1x2 tiles).
+// CH = 4: 64 rows = one 64-slot board per workgroup (smaller batches still), wave w owns the 32 pixels of half w>>1
+//         and the 32 couts of half w&1 (one tile).
 // 2-byte activations only: f32 rows (2 chunks) would need 128 KiB besides the weight ring.
 constexpr int R_LDS_W = 0;                    // 3 x 24 KiB
 constexpr int R_LDS_ACT = 3 * V2_SLAB;        // 2 x (ROWS x 128 B + a 128-byte zero row behind them)
@@ -696,7 +710,9 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     typedef __bf16 T;
     typedef Mfma<T>::frag frag;
     constexpr int ROWS = 256 / CH;      // tower rows of this workgroup
-    constexpr int CB = 2 / CH;          // 32-cout blocks per consumer wave
+    constexpr int CB = CH == 1 ? 2 : 1;  // 32-cout blocks per consumer wave
+    constexpr int NPB = CH == 4 ? 1 : 2; // 32-pixel blocks per consumer wave
+    static_assert(!(BIG && CH == 4), "a 128-slot board needs 128 rows in one workgroup");
     constexpr int ZERO_OFF = ROWS * 128;       // the zero row of a buffer (padding pixels read it), behind its rows
     constexpr int ACT_BYTES = ZERO_OFF + 128;  // buffer stride
     constexpr int SLOTS_PER_BOARD = BIG ? 128 : 64;
@@ -790,18 +806,19 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
 
     // ================================ consumer waves ================================
     const int r = lane & 31, h = lane >> 5;
-    const int rb = CH == 2 ? wave >> 1 : wave;             // 64-row block of this wave
-    const int coutb = CH == 2 ? (wave & 1) * 32 : 0;       // first output channel of this wave
+    const int rb = CH == 1 ? wave : CH == 2 ? wave >> 1 : 0;  // 64-row block of this wave
+    const int pb0 = CH == 4 ? wave >> 1 : 0;                  // first 32-pixel block of this wave inside its row block
+    const int coutb = CH == 1 ? 0 : (wave & 1) * 32;          // first output channel of this wave
     const int pslot0 = BIG ? (rb & 1) * 64 : 0;
     const int board_lds = BIG ? (rb >> 1) * 16384 : rb * 8192;
     // Activation fragment addresses, relative to the input buffer: per (kernel row, tap column, pixel block) the
     // byte offset of the shifted pixel's row (the buffer's zero row for pixels off the board) and the row's
     // swizzle term.  They depend on nothing but the lane, so they are made once; a step adds the buffer base.
-    bool pvalid[2];
-    int rel[3][3][2], swz[3][3][2];
+    bool pvalid[NPB];
+    int rel[3][3][NPB], swz[3][3][NPB];
 #pragma unroll
-    for (int pb = 0; pb < 2; pb++) {
-        const int p = pslot0 + pb * 32 + r;
+    for (int pb = 0; pb < NPB; pb++) {
+        const int p = pslot0 + (pb0 + pb) * 32 + r;
         const int ph = p / S, pw = p - ph * S;
         pvalid[pb] = p < S * S;
 #pragma unroll
@@ -824,17 +841,17 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     }
     // LDS address of this lane's 4-cout group (cb, g4) in pixel row (pb) of a buffer: 8 bytes at
     // row*128 + swizzled 16-byte slot of the cout + h*8
-    int eaddr[2];  // per pb: byte offset of the pixel row inside a buffer
-    int eswz[2];
+    int eaddr[NPB];  // per pb: byte offset of the pixel row inside a buffer
+    int eswz[NPB];
 #pragma unroll
-    for (int pb = 0; pb < 2; pb++) {
-        const int row = rb * 64 + pb * 32 + r;
+    for (int pb = 0; pb < NPB; pb++) {
+        const int row = rb * 64 + (pb0 + pb) * 32 + r;
         eaddr[pb] = row * 128 + h * 8;
         eswz[pb] = (row >> 1) & 7;
     }
 
-    // fragments are read AHEAD stages before the MFMAs that use them; a stage is CB * 2 MFMAs
-    constexpr int AHEAD = CB == 2 ? 2 : 3, RING = AHEAD + 1;
+    // fragments are read AHEAD stages before the MFMAs that use them; a stage is CB * NPB MFMAs
+    constexpr int AHEAD = CH == 1 ? 2 : CH == 2 ? 3 : 5, RING = AHEAD + 1;
     int opaque = 0;
     frag wa[4];       // head conv weights of this lane's head channel row
     f32x4 hbias[4];   // head conv bias of the 16 head channels this lane's accumulator holds
@@ -862,11 +879,11 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
 #pragma unroll
             for (int q = 0; q < 4; q++) hbias[q] = *reinterpret_cast<const f32x4*>(A.head_b + 8 * q + 4 * h);
         }
-        f32x16 acc[CB][2];
+        f32x16 acc[CB][NPB];
 #pragma unroll
         for (int i = 0; i < CB; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < NPB; j++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
@@ -882,36 +899,36 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
             if (layer == 0 && g == 0) STAMP(1);
             asm volatile("" : "+v"(opaque));  // keeps the per-step addresses from being hoisted out of the layer loop
             const int wslab = g * V2_SLAB;
-            int baddr[3][2][4];
+            int baddr[3][NPB][4];
 #pragma unroll
             for (int dxi = 0; dxi < 3; dxi++)
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) {
+                for (int pb = 0; pb < NPB; pb++) {
                     const int rowa = ibase + rel[g][dxi][pb] + opaque;
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (swz[g][dxi][pb] ^ (ks << 5));
                 }
-            frag fa[RING][CB], fb[RING][2];
-            auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[2]) {
+            frag fa[RING][CB], fb[RING][NPB];
+            auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[NPB]) {
                 const int dxi = i >> 2, ks = i & 3;
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++)
                     a[cb] = *reinterpret_cast<const frag*>(smem + aaddr[ks][cb] + (wslab + dxi * 8192));
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][ks]);
+                for (int pb = 0; pb < NPB; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][ks]);
             };
 #pragma unroll
             for (int i = 0; i < AHEAD; i++) load_stage(i, fa[i % RING], fb[i % RING]);
-            __builtin_amdgcn_sched_group_barrier(0x100, (CB + 2) * AHEAD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (CB + NPB) * AHEAD, 0);
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 if (i + AHEAD < 12) load_stage(i + AHEAD, fa[(i + AHEAD) % RING], fb[(i + AHEAD) % RING]);
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-                    for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
-                if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, CB + 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, CB * 2, 0);
+                    for (int pb = 0; pb < NPB; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
+                if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, CB + NPB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CB * NPB, 0);
             }
         }
 
@@ -920,11 +937,11 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
         // sends off-board taps to the zero row) and the heads skip them.
         STAMP_ACC_BEGIN;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        int eoff[CB][2][4];
+        int eoff[CB][NPB][4];
 #pragma unroll
         for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-            for (int pb = 0; pb < 2; pb++)
+            for (int pb = 0; pb < NPB; pb++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int slot16 = (coutb >> 3) + cb * 4 + g;  // 16-byte slot of couts coutb + cb*32 + g*8 .. +7
@@ -946,17 +963,17 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
         };
         if (L.res) {  // the block input lives in the buffer being overwritten: same addresses, all read first
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-            u32x2 rv[CB][2][4];
+            u32x2 rv[CB][NPB][4];
 #pragma unroll
             for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++)
+                for (int pb = 0; pb < NPB; pb++)
 #pragma unroll
                     for (int g = 0; g < 4; g++) rv[cb][pb][g] = *reinterpret_cast<const u32x2*>(smem + eoff[cb][pb][g]);
 #pragma unroll
             for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++)
+                for (int pb = 0; pb < NPB; pb++)
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const u32x2 w = rv[cb][pb][g];  // 4 bf16: a bf16 is the high half of the f32 with the same value
@@ -968,7 +985,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
 #pragma unroll
             for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++)
+                for (int pb = 0; pb < NPB; pb++)
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         // adding +0.0 leaves every value as it is (x + 0 == x, also for -0 + +0 = +0 before the ReLU)
@@ -985,12 +1002,14 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     const int fin = (nlayers & 1) ? 0 : 1;  // the stem and every second conv of a block write buffer 0
     if (A.head_w) {
         // D[i][px] = sum_k W[i][k] * X[px][k]: A = head weights [32][64] (rows >= ocn are zero), B = tower rows.
-        // CH = 1: the wave covers its 64 rows (2 pixel blocks); CH = 2: the two waves of a row block take one each.
-        constexpr int NPB = CH == 2 ? 1 : 2;
+        // CH = 1: the wave covers its 64 rows (2 pixel blocks); CH = 2: the two waves of a row block take one each;
+        // CH = 4: the first wave of each pixel block takes it.
+        constexpr int HPB = CH == 1 ? 2 : 1;
         const int hwp = S * S;
 #pragma unroll
-        for (int pbi = 0; pbi < NPB; pbi++) {
-            const int pb = CH == 2 ? (wave & 1) : pbi;
+        for (int pbi = 0; pbi < HPB; pbi++) {
+            if (CH == 4 && (wave & 1)) break;
+            const int pb = CH == 1 ? pbi : CH == 2 ? (wave & 1) : pb0;
             const int row = rb * 64 + pb * 32 + r;
             f32x16 hacc;
 #pragma unroll
@@ -1019,7 +1038,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     if (A.out) {
         const int prow = lane >> 3, sl = lane & 7;
         constexpr int RPW = 64 / CH;  // rows this wave stores
-        const int lrow0 = rb * 64 + (CH == 2 ? (wave & 1) * 32 : 0);
+        const int lrow0 = CH == 4 ? wave * 16 : rb * 64 + (CH == 2 ? (wave & 1) * 32 : 0);
         T* out = reinterpret_cast<T*>(A.out);
 #pragma unroll
         for (int i = 0; i < RPW / 8; i++) {
@@ -1044,7 +1063,9 @@ void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, hipStream_t 
         hipExtLaunchKernelGGL((tower64_lds_kernel<CH, BIG>), dim3(rows / (256 / CH)), dim3(512), tower64_lds_bytes(CH), st, ev_start, \
                               ev_stop, 0, args);                                                                \
     } while (0)
-    if (ch == 2) {
+    if (ch == 4 && !big) {
+        CATTUS_LAUNCH_T64(4, false);
+    } else if (ch == 2 || ch == 4) {
         if (big) CATTUS_LAUNCH_T64(2, true);
         else CATTUS_LAUNCH_T64(2, false);
     } else {
@@ -1102,7 +1123,7 @@ void launch_conv3x3_generic(const float* in, const float* w, const float* bias, 
 // Every dot product of the heads runs over k in 8-groups ascending and 0,4,1,5,2,6,3,7 inside a
 // group -- the order an MFMA lane pair (k = 4h + j) produces -- in the MFMA kernels, in the SIMT
 // kernels of the generic path, and in the CPU oracle alike.
-__device__ __forceinline__ uint32_t kperm(uint32_t kk) { return (kk & ~7u) + ((kk & 1u) << 2) + ((kk & 7u) >> 1); }
+__host__ __device__ constexpr uint32_t kperm(uint32_t kk) { return (kk & ~7u) + ((kk & 1u) << 2) + ((kk & 7u) >> 1); }
 
 // ---- MFMA path: D[i][j] = sum_k P[i][k] * Q[j][k], P and Q row-major with K contiguous -----
 // One wave per 32x32 tile, fragments straight from global memory (the operands are small and
@@ -1117,21 +1138,24 @@ struct HeadEpi {
 
 // A block = 4 waves = a 32 (i) x 128 (j) strip: wave w owns j tile tj0 + w.  The operands go through LDS in chunks of
 // 256 bytes per row, fetched with whole-line loads (16 lanes per row; a fragment read straight from memory touches 32
-// lines per instruction and uses a quarter of each -- the heads were bound by that, not by bytes) and double-buffered
-// in registers, so a chunk's round trip to L2 hides under the previous chunk's MFMAs.  The MFMA order over k is
+// lines per instruction and uses a quarter of each -- the heads were bound by that, not by bytes), HG_DEPTH chunks
+// ahead in registers.  The MFMA order over k is
 // unchanged, so results are bit for bit those of the direct-load version.
 constexpr int HG_ROWB = 256;                    // operand bytes per row and chunk: 128 bf16 / 64 f32 = 8 MFMA stages
 constexpr int HG_PITCH = HG_ROWB + 16;          // LDS row pitch: ds_read_b128 down a column of rows is conflict-free
 constexpr int HG_LDS = (32 + 128) * HG_PITCH;   // P rows 0..31, Q rows 32..159
 constexpr int HG_PIECES = (32 + 128) * (HG_ROWB / 16) / 256;  // 16-byte pieces per thread and chunk (10)
+constexpr int HG_DEPTH = 3;                     // chunks in flight per thread (registers)
+constexpr int HG_GROUP = 8;                     // chunks per straight-line group (1024 bf16 / 512 f32 k)
 
 template <typename T, int EPI>
 __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t ldp, uint32_t I, const T* __restrict__ Q,
                                                uint32_t ldq, uint32_t J, uint32_t K, const HeadEpi& ep, uint32_t bx,
-                                               uint32_t by, char* lds, float* stage = nullptr) {
+                                               uint32_t by, char* lds, float* stage HSTAMP_PARAM) {
     typedef typename Mfma<T>::frag frag;
     constexpr uint32_t KSTEP = 32 / sizeof(T);       // k per MFMA stage: 16 (bf16) or 8 (f32)
     constexpr uint32_t KCH = HG_ROWB / sizeof(T);    // k per chunk
+    constexpr uint32_t NST = KCH / KSTEP;            // MFMA stages per chunk (8)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
     const uint32_t i0 = by * 32, jb0 = bx * 128, j0 = jb0 + wave * 32;
@@ -1147,37 +1171,82 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
                           : reinterpret_cast<const char*>(Q + (size_t)min(jb0 + row - 32, J - 1) * ldq);
         dst[t] = row * HG_PITCH + colb[t];
     }
-    const uint32_t kbytes = K * sizeof(T);
-    f32x4 pre[HG_PIECES];
-    auto fetch = [&](uint32_t c) {
+    // K is a multiple of 16 elements on every caller (filters and head widths are padded by the evaluator), so a row
+    // has at least two 16-byte pieces.  HG_DEPTH chunks are in flight in registers: the heads are a chain of L2
+    // round trips (few blocks, operands cold), so the chunks a block will need are requested up front and refilled
+    // as they are consumed.  The loads are unconditional (address clamped to the row's last piece; a piece beyond K
+    // is zeroed when it is written to LDS): a load under a branch makes the compiler drain every outstanding load at
+    // the loop head, which serialises the look-ahead.
+    const uint32_t kbytes = K * sizeof(T), lastb = kbytes - 16;
+    f32x4 pre[HG_DEPTH][HG_PIECES];
+    auto fetch = [&](int s, uint32_t c) {
+#pragma unroll
+        for (int t = 0; t < HG_PIECES; t++)
+            pre[s][t] = *reinterpret_cast<const f32x4*>(src[t] + min(c * HG_ROWB + colb[t], lastb));
+    };
+    auto put = [&](int s, uint32_t c) {
 #pragma unroll
         for (int t = 0; t < HG_PIECES; t++) {
-            const uint32_t off = c * HG_ROWB + colb[t];
-            pre[t] = off < kbytes ? *reinterpret_cast<const f32x4*>(src[t] + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 v = pre[s][t];
+            if (c * HG_ROWB + colb[t] >= kbytes) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(lds + dst[t]) = v;
         }
     };
+    // epilogue operands requested now, so that their round trip is not paid after the last MFMA
+    const uint32_t j = j0 + r;
+    float bias_j = 0.0f;
+    f32x4 bias_i[4];
+    if constexpr (EPI == EPI_HEADCONV) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) bias_i[g] = *reinterpret_cast<const f32x4*>(ep.bias + 8 * g + 4 * h);  // 32 entries (padded)
+    } else {
+        bias_j = ep.bias[min(j, J - 1)];
+    }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.0f;
     const uint32_t nchunks = (K + KCH - 1) / KCH;
     const char* arow = lds + r * HG_PITCH + h * 16;
     const char* brow = lds + (32 + wave * 32 + r) * HG_PITCH + h * 16;
-    fetch(0);
-    for (uint32_t c = 0; c < nchunks; c++) {
+    // Groups of HG_GROUP chunks as straight-line code (the look-ahead does not cross a group boundary: with loads in
+    // flight around a loop's back edge the compiler drains all of them at the loop head)
+    for (uint32_t g0 = 0; g0 < nchunks; g0 += HG_GROUP) {
 #pragma unroll
-        for (int t = 0; t < HG_PIECES; t++) *reinterpret_cast<f32x4*>(lds + dst[t]) = pre[t];
-        __syncthreads();
-        if (c + 1 < nchunks) fetch(c + 1);
-        if (active) {
+        for (int s = 0; s < HG_DEPTH; s++) fetch(s, g0 + s);
 #pragma unroll
-            for (uint32_t u = 0; u < KCH / KSTEP; u++)
-                if (c * KCH + u * KSTEP < K)
-                    Mfma<T>::mac(*reinterpret_cast<const frag*>(arow + u * 32), *reinterpret_cast<const frag*>(brow + u * 32), acc);
+        for (int q = 0; q < HG_GROUP; q++) {
+            const uint32_t c = g0 + q;
+            if (c >= nchunks) break;
+            if (c == 1) STAMP(1);
+            put(q % HG_DEPTH, c);
+            if (c == 1) STAMP(2);
+            __syncthreads();
+            if (q + HG_DEPTH < HG_GROUP) fetch(q % HG_DEPTH, c + HG_DEPTH);
+            if (c == 1) STAMP(3);
+            if (active) {
+                const uint32_t left = K - c * KCH;
+                if (left >= KCH) {  // whole chunk: every fragment read is issued before the first MFMA needs one
+                    frag fa[NST], fb[NST];
+#pragma unroll
+                    for (uint32_t u = 0; u < NST; u++) {
+                        fa[u] = *reinterpret_cast<const frag*>(arow + u * 32);
+                        fb[u] = *reinterpret_cast<const frag*>(brow + u * 32);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < NST; u++) Mfma<T>::mac(fa[u], fb[u], acc);
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < NST; u++)
+                        if (u * KSTEP < left)
+                            Mfma<T>::mac(*reinterpret_cast<const frag*>(arow + u * 32), *reinterpret_cast<const frag*>(brow + u * 32), acc);
+                }
+            }
+            if (c == 1) STAMP(4);
+            __syncthreads();
         }
-        __syncthreads();
     }
+    STAMP(5);
     if (!active) return;
-    const uint32_t j = j0 + r;
     if (j >= J) return;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
@@ -1187,15 +1256,15 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
             // i = head channel (value rows first), j = tower row b*64 + p
             const uint32_t bb = j / ep.slots, p = j % ep.slots;
             if (i >= ep.ocn || p >= ep.hw) continue;
-            const float y = acc[e] + ep.bias[i];
+            const float y = acc[e] + bias_i[e >> 2][e & 3];
             const uint32_t col = i < ep.vhc ? i * ep.hw + p : ep.kvp + (i - ep.vhc) * ep.hw + p;
             reinterpret_cast<T*>(ep.out)[(size_t)bb * ep.hvs + col] = (T)(y > 0.0f ? y : 0.0f);
         } else if constexpr (EPI == EPI_FC1) {
-            const float y = acc[e] + ep.bias[j];
-            reinterpret_cast<float*>(ep.out)[(size_t)i * 128 + j] = y > 0.0f ? y : 0.0f;
+            const float y = acc[e] + bias_j;
             if (stage) stage[(i - i0) * 129 + j] = y > 0.0f ? y : 0.0f;  // [32 leaves][128 hidden], padded rows
+            else reinterpret_cast<float*>(ep.out)[(size_t)i * 128 + j] = y > 0.0f ? y : 0.0f;
         } else {
-            float y = acc[e] + ep.bias[j];
+            float y = acc[e] + bias_j;
             // non-finite logits -> f32::MIN (reference: engine/src/net/mod.rs:56-61)
             if (!(__builtin_fabsf(y) <= 3.40282347e+38f)) y = -3.40282347e+38f;
             reinterpret_cast<float*>(ep.out)[(size_t)i * ep.M + j] = y;
@@ -1208,40 +1277,53 @@ __global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P,
                                                         const T* __restrict__ Q, uint32_t ldq, uint32_t J, uint32_t K,
                                                         HeadEpi ep) {
     __shared__ __attribute__((aligned(16))) char hg_lds[HG_LDS];
-    head_gemm_tile<T, EPI>(P, ldp, I, Q, ldq, J, K, ep, blockIdx.x, blockIdx.y, hg_lds);
+    STAMP_DECL;
+    head_gemm_tile<T, EPI>(P, ldp, I, Q, ldq, J, K, ep, blockIdx.x, blockIdx.y, hg_lds, nullptr HSTAMP_PASS);
 }
 
-// Value FC1 and policy FC read the same head activations and do not depend on each other: one launch,
-// the first `fc1_blocks` block columns do FC1, the rest the policy FC (same tile code, same arithmetic).
-struct HeadFcPair {
-    const void *p1, *q1, *p2, *q2;
-    uint32_t ldp, I, ldq1, J1, K1, ldq2, J2, K2, fc1_blocks;
+// Value FC1 and policy FC read the same head activations and do not depend on each other: one launch, block column 0
+// does FC1 (128 hidden units = one strip), the others the policy FC (same tile code, same arithmetic).  What the first
+// loads need travels as plain kernel arguments (preloaded into SGPRs with the wave); the rest, in the struct, is
+// fetched by a scalar load that nothing waits on until the first LDS write.
+struct HeadFcTail {
     HeadEpi ep1, ep2;
     const float *w2, *b2;
     float* value;
 };
 __device__ __forceinline__ float tanh_exact(float x);
 template <typename T>
-__global__ void __launch_bounds__(256) head_fc_pair_kernel(HeadFcPair a) {
+__global__ void __launch_bounds__(256) head_fc_pair_kernel(const T* __restrict__ p1, const T* __restrict__ q1,
+                                                           const T* __restrict__ p2, const T* __restrict__ q2, uint32_t ldp,
+                                                           uint32_t I, uint32_t ldq1, uint32_t K1, uint32_t ldq2, uint32_t J2,
+                                                           uint32_t K2, HeadFcTail a) {
     __shared__ __attribute__((aligned(16))) char hg_lds[HG_LDS];
-    if (blockIdx.x < a.fc1_blocks) {
+    STAMP_DECL;
+    STAMP(0);
+    if (blockIdx.x == 0) {
         // The block's four waves hold all 128 hidden units of 32 leaves: stage them in LDS and finish the
         // value head here (FC2 + tanh, the fmaf chain of value_fc2_tanh_kernel), saving a launch.
         __shared__ float h1s[32 * 129];
-        head_gemm_tile<T, EPI_FC1>((const T*)a.p1, a.ldp, a.I, (const T*)a.q1, a.ldq1, a.J1, a.K1, a.ep1, blockIdx.x, blockIdx.y, hg_lds, h1s);
+        head_gemm_tile<T, EPI_FC1>(p1, ldp, I, q1, ldq1, 128, K1, a.ep1, 0, blockIdx.y, hg_lds, h1s HSTAMP_PASS);
         __syncthreads();
         const uint32_t leaf = blockIdx.y * 32 + threadIdx.x;
-        if (threadIdx.x < 32 && leaf < a.I) {
+        if (threadIdx.x < 32 && leaf < I) {
+            float hrow[128];
+#pragma unroll
+            for (uint32_t k = 0; k < 128; k++) hrow[k] = h1s[threadIdx.x * 129 + k];
             float acc = 0.0f;
+#pragma unroll
             for (uint32_t kk = 0; kk < 128; kk++) {
-                const uint32_t j = kperm(kk);
-                acc = __builtin_fmaf(a.w2[j], h1s[threadIdx.x * 129 + j], acc);
+                const uint32_t k = kperm(kk);
+                acc = __builtin_fmaf(a.w2[k], hrow[k], acc);
             }
             a.value[leaf] = tanh_exact(acc + a.b2[0]);
         }
-    } else
-        head_gemm_tile<T, EPI_POLICY>((const T*)a.p2, a.ldp, a.I, (const T*)a.q2, a.ldq2, a.J2, a.K2, a.ep2,
-                                      blockIdx.x - a.fc1_blocks, blockIdx.y, hg_lds);
+        STAMP(6);
+    } else {
+        head_gemm_tile<T, EPI_POLICY>(p2, ldp, I, q2, ldq2, J2, K2, a.ep2, blockIdx.x - 1, blockIdx.y, hg_lds, nullptr HSTAMP_PASS);
+        STAMP(6);
+    }
+    HSTAMP_FLUSH;
 }
 
 template <int EPI>
@@ -1268,18 +1350,18 @@ void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, cons
     // K4 + K5 in one launch: value FC1 (+ReLU): i = leaf, j = hidden unit; policy FC: i = leaf, j = move
     const size_t esz = act == Act::BF16 ? 2 : 4;
     if (!nb) return;
-    HeadFcPair a{};
-    a.p1 = hd.hv, a.q1 = hd.w1, a.p2 = (const char*)hd.hv + (size_t)hd.kvp * esz, a.q2 = hd.wp;
-    a.ldp = ep.hvs, a.I = nb;
-    a.ldq1 = hd.kvp, a.J1 = 128, a.K1 = hd.kvp;
-    a.ldq2 = hd.kpp, a.J2 = hd.M, a.K2 = hd.kpp;
-    a.fc1_blocks = (128 / 32 + 3) / 4;
+    HeadFcTail a{};
     a.ep1 = ep, a.ep1.bias = hd.b1, a.ep1.out = hd.h1;
     a.ep2 = ep, a.ep2.bias = hd.bp, a.ep2.out = hd.policy;
     a.w2 = hd.w2, a.b2 = hd.b2, a.value = hd.value;
-    const dim3 grid(a.fc1_blocks + ((hd.M + 31) / 32 + 3) / 4, (nb + 31) / 32), block(256);
-    if (act == Act::BF16) hipLaunchKernelGGL(head_fc_pair_kernel<__bf16>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(head_fc_pair_kernel<float>, grid, block, 0, st, a);
+    const void* p2 = (const char*)hd.hv + (size_t)hd.kvp * esz;
+    const dim3 grid(1 + ((hd.M + 31) / 32 + 3) / 4, (nb + 31) / 32), block(256);
+    if (act == Act::BF16)
+        hipLaunchKernelGGL(head_fc_pair_kernel<__bf16>, grid, block, 0, st, (const __bf16*)hd.hv, (const __bf16*)hd.w1,
+                           (const __bf16*)p2, (const __bf16*)hd.wp, ep.hvs, nb, hd.kvp, hd.kvp, hd.kpp, hd.M, hd.kpp, a);
+    else
+        hipLaunchKernelGGL(head_fc_pair_kernel<float>, grid, block, 0, st, (const float*)hd.hv, (const float*)hd.w1,
+                           (const float*)p2, (const float*)hd.wp, ep.hvs, nb, hd.kvp, hd.kvp, hd.kpp, hd.M, hd.kpp, a);
 }
 
 // ---- SIMT path (generic tower layout, any shape), same term order ---------------------------

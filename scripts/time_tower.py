@@ -17,7 +17,7 @@ for wl in args:
     d, blob, planes = bench.make_workload(wl.split(":")[0])
     n = batch or len(planes)
     dtype = "f32" if wl.endswith(":f32") else "bf16"
-    ev = HipEvaluator(blob, batch_size=len(planes), plane_words=planes.shape[2], dtype=dtype)
+    ev = HipEvaluator(blob, batch_size=max(n, len(planes)), plane_words=planes.shape[2], dtype=dtype)
     ev.time_tower(n, warm)
     us, launches = ev.time_tower(n, 200 if dtype == "bf16" else 20)
     print(wl, "tower launch us:", round(us, 2), "x", launches, end="  |  ")

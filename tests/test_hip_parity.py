@@ -138,6 +138,31 @@ def test_resident_tower_equals_per_layer_launches(game, desc, words, n, monkeypa
         assert ev.time_tower(min(n, 8), 1)[1] == 1  # one tower launch per forward
 
 
+def test_resident_tower_row_splits_agree(monkeypatch):
+    """The resident tower picks 256-, 128- or 64-row workgroups (CH = 1, 2, 4) by batch size; the split changes
+    which wave holds which tile, not the arithmetic of an output element: forced one after the other on the same
+    batch (CATTUS_T64_CH, read per forward pass) they give the bits of the per-layer launches."""
+    d = NetDesc(**hex_game(7), blocks=4, filters=64, vhc=16, phc=16)
+    blob = seeded_blob(d, 23)
+    rng = np.random.default_rng(9)
+    n = 203
+    planes = np.zeros((n, d.planes, 2), dtype=np.uint64)
+    bits = rng.integers(0, 2, size=(n, d.planes, 49), dtype=np.uint64)
+    for i in range(49):
+        planes[:, :, i >> 6] |= bits[:, :, i] << np.uint64(i & 63)
+    monkeypatch.setenv("CATTUS_TOWER64", "0")
+    with HipEvaluator(blob, batch_size=n, plane_words=2, dtype="bf16") as ev:
+        want_p, want_v = ev.eval(planes)
+    monkeypatch.delenv("CATTUS_TOWER64")
+    with HipEvaluator(blob, batch_size=n, plane_words=2, dtype="bf16") as ev:
+        for ch in ("4", "2", "1", "4"):
+            monkeypatch.setenv("CATTUS_T64_CH", ch)
+            got_p, got_v = ev.eval(planes)
+            assert (got_p == want_p).all() and (got_v == want_v).all(), ch
+            one_p, one_v = ev.eval(planes[77:78])
+            assert (one_p[0] == want_p[77]).all() and one_v[0] == want_v[77], ch
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("name", ["chess_20x256", "hex11_2x8"])
 def test_fused_stem_equals_separate_plane_pack(name, dtype, monkeypatch):
