@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end self-play throughput on one GPU: chess 20x256 bf16, batch 256.
 
-    python scripts/e2e_selfplay.py THREADS SLOTS SIMS GAMES [diverse] [devsoftmax] [serial] [lif=K]
+    python scripts/e2e_selfplay.py THREADS SLOTS SIMS GAMES [diverse] [devsoftmax] [serial] [lif=K] [batch=B] [plies=P]
 
 ``diverse`` uses the reference's self-play settings (temperature 1.0 for the first 30 moves,
 Dirichlet noise 0.03/0.25: training/config/chess_dev.yaml:52-68,83-88) so that games differ and the
@@ -20,18 +20,20 @@ threads, slots, sims, games = (int(x) for x in sys.argv[1:5])
 diverse = "diverse" in sys.argv[5:]
 eval_threads = 1 if "serial" in sys.argv[5:] else 2  # batches in flight
 lif = max([int(a[4:]) for a in sys.argv[5:] if a.startswith("lif=")] or [1])  # leaves in flight per tree (virtual loss)
+batch = max([int(a[6:]) for a in sys.argv[5:] if a.startswith("batch=")] or [256])  # leaves per batch (search side)
+plies = max([int(a[6:]) for a in sys.argv[5:] if a.startswith("plies=")] or [0])  # adjudicate after this many plies (0: play out)
 devsoftmax = "devsoftmax" in sys.argv[5:]  # legal-move softmax on the GPU (cattus_hip_eval_legal)
 d = NetDesc(**CHESS, blocks=20, filters=256, vhc=8, phc=8)
 blob = seeded_blob(d, 2)
 with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="bf16") as ev:
     kw = dict(temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25) if diverse else {}
-    cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000, eval_threads=eval_threads, leaves_in_flight=lif, **kw)
+    cfg = sp.make_config(sim_num=sims, batch_size=batch, max_game_plies=plies, threads=threads, concurrent_games=slots, cache_size=1000000, eval_threads=eval_threads, leaves_in_flight=lif, **kw)
     t = time.time()
     res = sp.run_self_play("chess", cfg, sp.Net.hip(ev, device_softmax=devsoftmax), None, games, keep_records=False)
     dt = time.time() - t
     st = ev.stats()
 print(json.dumps(dict(
-    threads=threads, slots=slots, sims=sims, games=games, diverse=diverse, device_softmax=devsoftmax, eval_threads=eval_threads, leaves_in_flight=lif, seconds=round(dt, 3),
+    threads=threads, slots=slots, sims=sims, games=games, diverse=diverse, device_softmax=devsoftmax, eval_threads=eval_threads, leaves_in_flight=lif, batch=batch, max_game_plies=plies, seconds=round(dt, 3),
     node_evals=res["node_evals"], evals_per_s=round(res["node_evals"] / dt),
     steady_evals_per_s=round(res["steady_node_evals"] / res["steady_seconds"]), steady_seconds=round(res["steady_seconds"], 2), batches=res["activation_count"],
     batch_fill=round(res["node_evals"] / max(1, res["activation_count"]), 1), positions=res["positions"],

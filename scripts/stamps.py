@@ -39,5 +39,11 @@ print(f"  loaders  : lifetime {np.median(load[...,3]-load[...,0]):.0f}, waiting 
       f"waiting at barriers {np.median(load[...,7]):.0f}; prologue {np.median(load[...,1]-load[...,0]):.0f}")
 mfma = {"bf16": 12 * 48 * 32, "f32": 24 * 192 * 64}[dtype]
 print(f"  MFMA-bound loop time {mfma} cycles -> loop efficiency {mfma/np.median(cons[...,2]-cons[...,1]):.2f}, kernel efficiency {mfma/np.median(tot):.2f}")
-skew = (cons[..., 3].max() - cons[..., 0].min())
-print(f"  first start -> last end over all workgroups: {skew:.0f} cycles")
+span = (cons[..., 6].max() - cons[..., 5].min()) / 100.0  # us on the 100 MHz real-time counter, one time base for all XCDs
+starts = (cons[..., 5] - cons[..., 5].min()) / 100.0
+ends = (cons[..., 6].max() - cons[..., 6]) / 100.0
+us, launches = ev.time_tower(256, 50)
+print(f"  first wave start -> last wave end over all workgroups: {span:.2f} us; event-stamped launch {us:.2f} us "
+      f"(the difference is dispatch before the first wave and completion after the last)")
+print(f"  wave start after the first one: median {np.median(starts):.2f} us, max {starts.max():.2f} us; "
+      f"wave end before the last one: median {np.median(ends):.2f} us, max {ends.max():.2f} us")
