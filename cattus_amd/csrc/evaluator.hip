@@ -471,7 +471,8 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
                 const int f = atoi(force);
                 ch = f == 1 ? 1 : (f == 4 && e->slots == 64) ? 4 : 2;
             }
-            launch_tower64(ta, rows, ch, st, s0, s1);
+            const bool layer_steps = !(getenv("CATTUS_T64_LS") && atoi(getenv("CATTUS_T64_LS")) == 0);
+            launch_tower64(ta, rows, ch, layer_steps, st, s0, s1);
         } else {
             // the stem conv expands the planes itself when they fit one 128-byte chunk (every game here); else K0 first
             const bool fused_stem = d.planes <= 32 && e->cpad0 == (uint32_t)act_kc(e->act) && !e->pack_separately;

@@ -202,7 +202,7 @@ __device__ unsigned long long g_hstamps[256 * 4 * 8];
 #define HSTAMP_PARAM , unsigned long long* st_
 #define HSTAMP_PASS , st_
 #define HSTAMP_FLUSH                                                                                  \
-    if ((threadIdx.x & 63) == 0 && blockIdx.y * gridDim.x + blockIdx.x < 256)                          \
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256 && blockIdx.y * gridDim.x + blockIdx.x < 256)    \
         for (int q_ = 0; q_ < 8; q_++) g_hstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + q_] = st_[q_]
 #else
 #define HSTAMP_PARAM
@@ -702,19 +702,25 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 //         and the 32 couts of half w&1 (one tile).
 // 2-byte activations only: f32 rows (2 chunks) would need 128 KiB besides the weight ring.
 constexpr int R_LDS_W = 0;                    // 3 x 24 KiB
-constexpr int R_LDS_ACT = 3 * V2_SLAB;        // 2 x (ROWS x 128 B + a 128-byte zero row behind them)
-constexpr int tower64_lds_bytes(int ch) { return R_LDS_ACT + 2 * ((256 / ch) * 128 + 128); }
+// behind the ring: 2 x (ROWS x 128 B + a 128-byte zero row)
+// LS (CH = 4, boards of <= 63 pixels): a layer is ONE step.  The ring holds two whole layers (6 slabs = 144 KiB), the
+// loaders run one layer ahead and there is one barrier per layer instead of three; the consumer's fragment pipeline
+// runs through all 36 stages of the layer.  The two 8 KiB activation buffers fill the rest of the 160 KiB exactly, so
+// there is no room for zero rows: pixel slot 63, which such a board does not use, is kept zero and serves as one.
+constexpr int tower64_lds_bytes(int ch, bool ls) { return ls ? 6 * V2_SLAB + 2 * 64 * 128 : 3 * V2_SLAB + 2 * ((256 / ch) * 128 + 128); }
 
-template <int CH, bool BIG>
+template <int CH, bool BIG, bool LS = false>
 __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
+    static_assert(!LS || CH == 4, "layer steps: one board per workgroup only");
+    constexpr int R_LDS_ACT = (LS ? 6 : 3) * V2_SLAB;
     typedef __bf16 T;
     typedef Mfma<T>::frag frag;
     constexpr int ROWS = 256 / CH;      // tower rows of this workgroup
     constexpr int CB = CH == 1 ? 2 : 1;  // 32-cout blocks per consumer wave
     constexpr int NPB = CH == 4 ? 1 : 2; // 32-pixel blocks per consumer wave
     static_assert(!(BIG && CH == 4), "a 128-slot board needs 128 rows in one workgroup");
-    constexpr int ZERO_OFF = ROWS * 128;       // the zero row of a buffer (padding pixels read it), behind its rows
-    constexpr int ACT_BYTES = ZERO_OFF + 128;  // buffer stride
+    constexpr int ZERO_OFF = LS ? 63 * 128 : ROWS * 128;    // the zero row of a buffer (padding pixels read it): behind its rows / slot 63
+    constexpr int ACT_BYTES = LS ? ROWS * 128 : ZERO_OFF + 128;  // buffer stride
     constexpr int SLOTS_PER_BOARD = BIG ? 128 : 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -742,6 +748,14 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
 #pragma unroll
         for (int i = 0; i < WPL; i++) glds16(src + off_w[i], dst + dst_w[i]);
     };
+    auto issue_layer = [&](int layer) {  // LS: the three slabs of a layer -> ring half layer & 1
+        const char* src = reinterpret_cast<const char*>(A.layers[layer].w);
+        char* dst = smem + R_LDS_W + (layer & 1) * 3 * V2_SLAB;
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+#pragma unroll
+            for (int i = 0; i < WPL; i++) glds16(src + (size_t)(g * 3) * 64 * 128 + off_w[i], dst + g * V2_SLAB + dst_w[i]);
+    };
     if (is_loader) {
         const int prow = lane >> 3, pslot = lane & 7;
 #pragma unroll
@@ -752,8 +766,13 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
             off_w[i] = ((uint32_t)(tap_i * 64 + row)) * 128 + c * 16;
             dst_w[i] = pid * 1024;
         }
-        issue_w(0);
-        if (T_total > 1) issue_w(1);
+        if constexpr (LS) {
+            issue_layer(0);
+            if (nlayers > 1) issue_layer(1);
+        } else {
+            issue_w(0);
+            if (T_total > 1) issue_w(1);
+        }
     }
 
     // ---- stem input: bitboard planes -> buffer 1, [row][64 ch], 1.0 where the plane has the pixel's bit ----
@@ -794,6 +813,16 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
 
     if (is_loader) {
         // ================================ loader waves: the weight stream ================================
+        if constexpr (LS) {
+            for (int layer = 0; layer < nlayers; layer++) {
+                // layer 1 went out with layer 0; from then on layer l+1 is issued when the consumers have passed barrier l
+                // (they are done with layer l-1, whose half it overwrites) and is waited for at barrier l+1
+                if (layer == 0 && nlayers > 1) wait_vm_barrier<3 * WPL>();
+                else wait_vm_barrier<0>();
+                if (layer >= 1 && layer + 1 < nlayers) issue_layer(layer + 1);
+            }
+            return;
+        }
         for (int t = 0; t < T_total; t++) {
             // step t's slab was issued two steps ago; only the slab of step t+1 may still be in flight
             if (t + 1 < T_total) wait_vm_barrier<WPL>();
@@ -887,6 +916,47 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
+        if constexpr (LS) {
+            {
+                STAMP_ACC_BEGIN;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                STAMP_ACC_END(4);
+            }
+            if (layer == 0) STAMP(1);
+            asm volatile("" : "+v"(opaque));
+            const int wbase = (layer & 1) * 3 * V2_SLAB;
+            int baddr[9][NPB][4];
+#pragma unroll
+            for (int t9 = 0; t9 < 9; t9++)
+#pragma unroll
+                for (int pb = 0; pb < NPB; pb++) {
+                    const int rowa = ibase + rel[t9 / 3][t9 % 3][pb] + opaque;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) baddr[t9][pb][ks] = rowa + (swz[t9 / 3][t9 % 3][pb] ^ (ks << 5));
+                }
+            frag fa[RING][CB], fb[RING][NPB];
+            auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[NPB]) {  // i = tap * 4 + ks, tap = g * 3 + dxi: slab g, tap row dxi
+                const int t9 = i >> 2, ks = i & 3;
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+                    a[cb] = *reinterpret_cast<const frag*>(smem + aaddr[ks][cb] + (wbase + (t9 / 3) * V2_SLAB + (t9 % 3) * 8192));
+#pragma unroll
+                for (int pb = 0; pb < NPB; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[t9][pb][ks]);
+            };
+#pragma unroll
+            for (int i = 0; i < AHEAD; i++) load_stage(i, fa[i % RING], fb[i % RING]);
+            __builtin_amdgcn_sched_group_barrier(0x100, (CB + NPB) * AHEAD, 0);
+#pragma unroll
+            for (int i = 0; i < 36; i++) {
+                if (i + AHEAD < 36) load_stage(i + AHEAD, fa[(i + AHEAD) % RING], fb[(i + AHEAD) % RING]);
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                    for (int pb = 0; pb < NPB; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
+                if (i + AHEAD < 36) __builtin_amdgcn_sched_group_barrier(0x100, CB + NPB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CB * NPB, 0);
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < 3; g++) {
             // fragment reads of the previous step and (at a layer boundary) the previous layer's output writes
@@ -931,6 +1001,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
                 __builtin_amdgcn_sched_group_barrier(0x008, CB * NPB, 0);
             }
         }
+        }
 
         // ---- layer epilogue: + bias (+ block input), ReLU, bf16, into the other buffer (same layout) ----
         // Pixel slots >= S*S are stored as they come: no conv ever reads them as a neighbour (the address table
@@ -961,6 +1032,13 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
             ov[0] = (T)v01[0], ov[1] = (T)v01[1], ov[2] = (T)v23[0], ov[3] = (T)v23[1];
             return ov;
         };
+        // LS: pixel slots the board does not have stay zero (slot 63 is the zero row of the next layer's taps)
+        auto keep = [&](bf16x4 ov, int pb) {
+            if constexpr (LS) {
+                if (!pvalid[pb]) ov = bf16x4{(T)0.0f, (T)0.0f, (T)0.0f, (T)0.0f};
+            }
+            return ov;
+        };
         if (L.res) {  // the block input lives in the buffer being overwritten: same addresses, all read first
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             u32x2 rv[CB][NPB][4];
@@ -979,7 +1057,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
                         const u32x2 w = rv[cb][pb][g];  // 4 bf16: a bf16 is the high half of the f32 with the same value
                         const f32x2 r01{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u)};
                         const f32x2 r23{__uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
-                        *reinterpret_cast<bf16x4*>(smem + eoff[cb][pb][g]) = finish(acc[cb][pb], g, biasv[cb][g], r01, r23);
+                        *reinterpret_cast<bf16x4*>(smem + eoff[cb][pb][g]) = keep(finish(acc[cb][pb], g, biasv[cb][g], r01, r23), pb);
                     }
         } else {
 #pragma unroll
@@ -990,7 +1068,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
                     for (int g = 0; g < 4; g++) {
                         // adding +0.0 leaves every value as it is (x + 0 == x, also for -0 + +0 = +0 before the ReLU)
                         *reinterpret_cast<bf16x4*>(smem + eoff[cb][pb][g]) =
-                            finish(acc[cb][pb], g, biasv[cb][g], f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f});
+                            keep(finish(acc[cb][pb], g, biasv[cb][g], f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}), pb);
                     }
         }
         STAMP_ACC_END(5);
@@ -1051,20 +1129,23 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     STAMP_FLUSH(wave);
 }
 
-void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, bool layer_steps, hipStream_t st, hipEvent_t ev_start,
+                    hipEvent_t ev_stop) {
     const bool big = tower_slots(args.S) == 128;
-#define CATTUS_LAUNCH_T64(CH, BIG)                                                                              \
+#define CATTUS_LAUNCH_T64_LS(CH, BIG, LS)                                                                       \
     do {                                                                                                        \
         static std::atomic<uint64_t> attr_set{0};                                                               \
         if (first_use_on_device(attr_set)) {                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower64_lds_kernel<CH, BIG>),             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, tower64_lds_bytes(CH));       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower64_lds_kernel<CH, BIG, LS>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, tower64_lds_bytes(CH, LS));   \
         }                                                                                                       \
-        hipExtLaunchKernelGGL((tower64_lds_kernel<CH, BIG>), dim3(rows / (256 / CH)), dim3(512), tower64_lds_bytes(CH), st, ev_start, \
-                              ev_stop, 0, args);                                                                \
+        hipExtLaunchKernelGGL((tower64_lds_kernel<CH, BIG, LS>), dim3(rows / (256 / CH)), dim3(512), tower64_lds_bytes(CH, LS), st, \
+                              ev_start, ev_stop, 0, args);                                                      \
     } while (0)
+#define CATTUS_LAUNCH_T64(CH, BIG) CATTUS_LAUNCH_T64_LS(CH, BIG, false)
     if (ch == 4 && !big) {
-        CATTUS_LAUNCH_T64(4, false);
+        if (layer_steps && args.S * args.S <= 63) CATTUS_LAUNCH_T64_LS(4, false, true);
+        else CATTUS_LAUNCH_T64(4, false);
     } else if (ch == 2 || ch == 4) {
         if (big) CATTUS_LAUNCH_T64(2, true);
         else CATTUS_LAUNCH_T64(2, false);
@@ -1073,6 +1154,7 @@ void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, hipStream_t 
         else CATTUS_LAUNCH_T64(1, false);
     }
 #undef CATTUS_LAUNCH_T64
+#undef CATTUS_LAUNCH_T64_LS
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1136,7 +1218,7 @@ struct HeadEpi {
     uint32_t hw, vhc, ocn, hvs, kvp, M, slots;
 };
 
-// A block = 4 waves = a 32 (i) x 128 (j) strip: wave w owns j tile tj0 + w.  The operands go through LDS in chunks of
+// A block = 8 waves = a 32 (i) x 128 (j) strip: wave w < 4 owns j tile tj0 + w, waves 4-7 only stage operands.  The operands go through LDS in chunks of
 // 256 bytes per row, fetched with whole-line loads (16 lanes per row; a fragment read straight from memory touches 32
 // lines per instruction and uses a quarter of each -- the heads were bound by that, not by bytes), HG_DEPTH chunks
 // ahead in registers.  The MFMA order over k is
@@ -1144,7 +1226,8 @@ struct HeadEpi {
 constexpr int HG_ROWB = 256;                    // operand bytes per row and chunk: 128 bf16 / 64 f32 = 8 MFMA stages
 constexpr int HG_PITCH = HG_ROWB + 16;          // LDS row pitch: ds_read_b128 down a column of rows is conflict-free
 constexpr int HG_LDS = (32 + 128) * HG_PITCH;   // P rows 0..31, Q rows 32..159
-constexpr int HG_PIECES = (32 + 128) * (HG_ROWB / 16) / 256;  // 16-byte pieces per thread and chunk (10)
+constexpr int HG_THREADS = 512;                 // waves 0-3 own the four j tiles; all eight stage the operands
+constexpr int HG_PIECES = (32 + 128) * (HG_ROWB / 16) / HG_THREADS;  // 16-byte pieces per thread and chunk (5)
 constexpr int HG_DEPTH = 3;                     // chunks in flight per thread (registers)
 constexpr int HG_GROUP = 8;                     // chunks per straight-line group (1024 bf16 / 512 f32 k)
 
@@ -1159,13 +1242,13 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
     const uint32_t i0 = by * 32, jb0 = bx * 128, j0 = jb0 + wave * 32;
-    const bool active = j0 < J;  // a wave without a tile still helps with the staging
-    // this thread's pieces: piece q = tid + 256 t -> LDS row q >> 4 (P rows first), 16-byte column q & 15
+    const bool active = wave < 4 && j0 < J;  // a wave without a tile still helps with the staging
+    // this thread's pieces: piece q = tid + HG_THREADS t -> LDS row q >> 4 (P rows first), 16-byte column q & 15
     const char* src[HG_PIECES];
     uint32_t dst[HG_PIECES], colb[HG_PIECES];
 #pragma unroll
     for (int t = 0; t < HG_PIECES; t++) {
-        const uint32_t q = tid + 256 * t, row = q >> 4;
+        const uint32_t q = tid + HG_THREADS * t, row = q >> 4;
         colb[t] = (q & 15) * 16;
         src[t] = row < 32 ? reinterpret_cast<const char*>(P + (size_t)min(i0 + row, I - 1) * ldp)
                           : reinterpret_cast<const char*>(Q + (size_t)min(jb0 + row - 32, J - 1) * ldq);
@@ -1273,7 +1356,7 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
 }
 
 template <typename T, int EPI>
-__global__ void __launch_bounds__(256) head_gemm_kernel(const T* __restrict__ P, uint32_t ldp, uint32_t I,
+__global__ void __launch_bounds__(HG_THREADS) head_gemm_kernel(const T* __restrict__ P, uint32_t ldp, uint32_t I,
                                                         const T* __restrict__ Q, uint32_t ldq, uint32_t J, uint32_t K,
                                                         HeadEpi ep) {
     __shared__ __attribute__((aligned(16))) char hg_lds[HG_LDS];
@@ -1292,7 +1375,7 @@ struct HeadFcTail {
 };
 __device__ __forceinline__ float tanh_exact(float x);
 template <typename T>
-__global__ void __launch_bounds__(256) head_fc_pair_kernel(const T* __restrict__ p1, const T* __restrict__ q1,
+__global__ void __launch_bounds__(HG_THREADS) head_fc_pair_kernel(const T* __restrict__ p1, const T* __restrict__ q1,
                                                            const T* __restrict__ p2, const T* __restrict__ q2, uint32_t ldp,
                                                            uint32_t I, uint32_t ldq1, uint32_t K1, uint32_t ldq2, uint32_t J2,
                                                            uint32_t K2, HeadFcTail a) {
@@ -1330,7 +1413,7 @@ template <int EPI>
 static void launch_head_gemm(Act act, const void* P, uint32_t ldp, uint32_t I, const void* Q, uint32_t ldq, uint32_t J,
                              uint32_t K, const HeadEpi& ep, hipStream_t st) {
     if (!I || !J) return;
-    const dim3 grid(((J + 31) / 32 + 3) / 4, (I + 31) / 32), block(256);
+    const dim3 grid(((J + 31) / 32 + 3) / 4, (I + 31) / 32), block(HG_THREADS);
     if (act == Act::BF16)
         hipLaunchKernelGGL((head_gemm_kernel<__bf16, EPI>), grid, block, 0, st, (const __bf16*)P, ldp, I, (const __bf16*)Q, ldq,
                            J, K, ep);
@@ -1355,7 +1438,7 @@ void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, cons
     a.ep2 = ep, a.ep2.bias = hd.bp, a.ep2.out = hd.policy;
     a.w2 = hd.w2, a.b2 = hd.b2, a.value = hd.value;
     const void* p2 = (const char*)hd.hv + (size_t)hd.kvp * esz;
-    const dim3 grid(1 + ((hd.M + 31) / 32 + 3) / 4, (nb + 31) / 32), block(256);
+    const dim3 grid(1 + ((hd.M + 31) / 32 + 3) / 4, (nb + 31) / 32), block(HG_THREADS);
     if (act == Act::BF16)
         hipLaunchKernelGGL(head_fc_pair_kernel<__bf16>, grid, block, 0, st, (const __bf16*)hd.hv, (const __bf16*)hd.w1,
                            (const __bf16*)p2, (const __bf16*)hd.wp, ep.hvs, nb, hd.kvp, hd.kvp, hd.kpp, hd.M, hd.kpp, a);

@@ -139,9 +139,10 @@ def test_resident_tower_equals_per_layer_launches(game, desc, words, n, monkeypa
 
 
 def test_resident_tower_row_splits_agree(monkeypatch):
-    """The resident tower picks 256-, 128- or 64-row workgroups (CH = 1, 2, 4) by batch size; the split changes
-    which wave holds which tile, not the arithmetic of an output element: forced one after the other on the same
-    batch (CATTUS_T64_CH, read per forward pass) they give the bits of the per-layer launches."""
+    """The resident tower picks 256-, 128- or 64-row workgroups (CH = 1, 2, 4) by batch size, and with 64 rows and a
+    board of <= 63 pixels walks a layer as one step; the split changes which wave holds which tile and when the
+    waves meet, not the arithmetic of an output element: forced one after the other on the same batch
+    (CATTUS_T64_CH / CATTUS_T64_LS, read per forward pass) they give the bits of the per-layer launches."""
     d = NetDesc(**hex_game(7), blocks=4, filters=64, vhc=16, phc=16)
     blob = seeded_blob(d, 23)
     rng = np.random.default_rng(9)
@@ -155,12 +156,13 @@ def test_resident_tower_row_splits_agree(monkeypatch):
         want_p, want_v = ev.eval(planes)
     monkeypatch.delenv("CATTUS_TOWER64")
     with HipEvaluator(blob, batch_size=n, plane_words=2, dtype="bf16") as ev:
-        for ch in ("4", "2", "1", "4"):
+        for ch, ls in (("4", "1"), ("2", "1"), ("4", "0"), ("1", "1"), ("4", "1")):
             monkeypatch.setenv("CATTUS_T64_CH", ch)
+            monkeypatch.setenv("CATTUS_T64_LS", ls)  # 64-row workgroups: one barrier per layer (default) or three
             got_p, got_v = ev.eval(planes)
-            assert (got_p == want_p).all() and (got_v == want_v).all(), ch
+            assert (got_p == want_p).all() and (got_v == want_v).all(), (ch, ls)
             one_p, one_v = ev.eval(planes[77:78])
-            assert (one_p[0] == want_p[77]).all() and one_v[0] == want_v[77], ch
+            assert (one_p[0] == want_p[77]).all() and one_v[0] == want_v[77], (ch, ls)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
