@@ -590,7 +590,8 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 if (!valid) y = 0.0f;
                 ov[j] = (T)y;
             }
-            // non-temporal: the line still stays in this XCD's L2 for the next layer, but leaves early
+            // non-temporal: the line leaves for memory early instead of at the kernel's end (plain stores: launch 18.35 ->
+            // 18.7 us, one batch at a time unchanged, two batches in flight +3 %, self-play +0.8 %; profiles/r02_experiments.txt)
             if (sizeof(T) == 2) {
                 __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(ov), reinterpret_cast<f32x4*>(out + off));
             } else {
