@@ -469,12 +469,14 @@ def main():
         from cattus_amd import selfplay as sp
 
         threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 4)
-        # BASELINE config 3 as written: 800 sims/move, batch 256; 1024 concurrent games (two batches in flight
-        # and two more ready to go); every game is cut after `plies` plies so that the leg fits its time budget (a whole
-        # 800-sim game of ~290 plies costs ~170 k evaluations, 1024 of them ~9 minutes of GPU time)
+        # BASELINE config 3 as written: 800 sims/move, batch 256; 1536 concurrent games (two batches in flight and four
+        # more in the making: with 1024 the two lanes are busy 76 % of the time each, with 1536 95 %, +4 % throughput);
+        # every game is cut after `plies` plies so that the leg fits its time budget (a whole 800-sim game of ~290 plies
+        # costs ~170 k evaluations, 1536 of them ~13 minutes of GPU time)
         capacity = min(330e3, threads * 60e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
-        plies = int(max(4, min(64, args.selfplay_seconds * capacity / (1024 * 0.75 * args.selfplay_sims))))
-        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=1024, slots=1024, sims=args.selfplay_sims, max_game_plies=plies,
+        conc = 1536
+        plies = int(max(4, min(64, args.selfplay_seconds * capacity / (conc * 0.75 * args.selfplay_sims))))
+        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=conc, slots=conc, sims=args.selfplay_sims, max_game_plies=plies,
                            keep_records=False, pool=False, torch=torch, dev=cdev)
         sp_out = reduce_leg(leg, torch, cdev, world)
         sp_out.update(max_game_plies=plies, settings=SELFPLAY_SETTINGS_TEXT,
