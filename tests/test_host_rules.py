@@ -48,6 +48,25 @@ def test_hip_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.cattus_hip_version()
 
 
+def test_loading_the_hip_library_defaults_kernel_arguments_to_device_memory():
+    """libcattus_hip.so asks the HIP runtime for a device-memory kernel-argument ring (HIP_FORCE_DEV_KERNARG=1, read when
+    the runtime initialises) from a load-time constructor, without overriding the environment."""
+    import subprocess
+    import sys
+
+    from cattus_amd import evaluator
+
+    lib = str(evaluator.library_path()) if hasattr(evaluator, "library_path") else evaluator.load_library()._name
+    code = ("import ctypes, sys; ctypes.CDLL(sys.argv[1]); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print((libc.getenv(b'HIP_FORCE_DEV_KERNARG') or b'unset').decode())")
+    import os
+
+    env = {k: v for k, v in os.environ.items() if k != "HIP_FORCE_DEV_KERNARG"}
+    assert subprocess.run([sys.executable, "-c", code, lib], env=env, capture_output=True, text=True, check=True).stdout.strip() == "1"
+    env["HIP_FORCE_DEV_KERNARG"] = "0"
+    assert subprocess.run([sys.executable, "-c", code, lib], env=env, capture_output=True, text=True, check=True).stdout.strip() == "0"
+
+
 # ------------------------------------------------------------------------------------------ ttt
 
 
