@@ -75,9 +75,11 @@ void launch_conv3x3_generic(const float* in, const float* w, const float* bias, 
 
 // ---- K3-K5: heads on MFMA (tuned tower layout) ----------------------------------------------
 // All matrices are in the tower element type `act` with K contiguous and zero-padded:
-//   conv_w [32][F] (value rows, then policy rows, rest zero), conv_b [vhc+phc] f32,
+//   conv_w [32][F] (value rows, then policy rows, rest zero), conv_b [32] f32 (entries >= vhc+phc zero),
 //   hv [nb][kvp+kpp] (value part at 0, policy part at kvp; pad columns stay zero),
-//   w1 [128][kvp], b1 [128] f32, h1 [nb][128] f32, wp [round32(M)][kpp], bp [M] f32, policy [nb][M] f32.
+//   w1 [128][kvp], b1 [128] f32, wp [round32(M)][kpp], bp [M] f32, policy [nb][M] f32;
+//   h1 [nb][128] f32 is scratch of the stand-alone FC1 (the fused FC launch keeps the hidden units in LDS).
+//   kvp, kpp and F are multiples of 16 elements (the k walk reads whole 16-byte pieces).
 struct HeadsMfma {
     const void* conv_w;
     const float* conv_b;
