@@ -462,15 +462,10 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             ta.head_w = e->head_w.p, ta.head_b = e->head_b.as<float>(), ta.hv = L.hv.p;
             ta.hvs = e->kvp + e->kpp, ta.kvp = e->kvp, ta.vhc = d.vhc, ta.ocn = d.vhc + d.phc;
             const uint32_t rows = nb * e->slots;
-            // 256-row workgroups once they fill the chip, else twice as many 128-row ones, else (64-slot boards) one
-            // board per workgroup while that still leaves no CU with two of them
+            // 128-row workgroups; for 64-slot boards one board per workgroup while that leaves no CU with two of them
             hipEvent_t s0 = ev(false), s1 = ev(true);
-            int ch = rows / ROWS_PER_WG >= 256 ? 1 : 2;
-            if (ch == 2 && e->slots == 64 && rows / 64 <= 256) ch = 4;
-            if (const char* force = getenv("CATTUS_T64_CH")) {  // A/B runs
-                const int f = atoi(force);
-                ch = f == 1 ? 1 : (f == 4 && e->slots == 64) ? 4 : 2;
-            }
+            int ch = e->slots == 64 && rows / 64 <= 256 ? 4 : 2;
+            if (const char* force = getenv("CATTUS_T64_CH")) ch = atoi(force) == 4 && e->slots == 64 ? 4 : 2;  // A/B runs
             const bool layer_steps = !(getenv("CATTUS_T64_LS") && atoi(getenv("CATTUS_T64_LS")) == 0);
             launch_tower64(ta, rows, ch, layer_steps, st, s0, s1);
         } else {

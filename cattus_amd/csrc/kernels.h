@@ -61,9 +61,9 @@ struct Tower64Args {
     void* hv;             // [boards][hvs] bf16
     uint32_t hvs, kvp, vhc, ocn;
 };
-// rows % (256 / ch) == 0; ch = 1: 256 rows per workgroup, ch = 2: 128 rows per workgroup (small batches), ch = 4: one
-// 64-slot board per workgroup (smaller still; 128-slot boards run as ch = 2).  layer_steps: with ch = 4 and boards of
-// <= 63 pixels, one barrier per layer instead of three (two layers of weights in LDS); same results.
+// rows % 256 == 0; ch = 2: 128 rows per workgroup, ch = 4: one 64-slot board per workgroup (small batches; 128-slot
+// boards run as ch = 2).  layer_steps: with ch = 4 and boards of <= 63 pixels, one barrier per layer instead of three
+// (two layers of weights in LDS); same results.
 void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, bool layer_steps, hipStream_t st,
                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 

@@ -696,11 +696,11 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 // Arithmetic per output element is that of the per-layer kernel, operation for operation (bf16 operands,
 // f32 accumulation in the same order, + bias, + skip, ReLU, one rounding to bf16), so results are bit-identical.
 //
-// CH = 1: 256 tower rows per workgroup, consumer wave w owns rows 64w..64w+63 x 64 couts (2x2 MFMA tiles).
-// CH = 2: 128 rows per workgroup (twice the workgroups: small batches), wave w owns row block w>>1 and the
-//         32 couts of half w&1 (1x2 tiles).
-// CH = 4: 64 rows = one 64-slot board per workgroup (smaller batches still), wave w owns the 32 pixels of half w>>1
-//         and the 32 couts of half w&1 (one tile).
+// CH = 2: 128 rows per workgroup, wave w owns row block w>>1 and the 32 couts of half w&1 (1x2 MFMA tiles).
+// CH = 4: 64 rows = one 64-slot board per workgroup (<= 256 boards), wave w owns the 32 pixels of half w>>1 and the
+//         32 couts of half w&1 (one tile).
+// (A 256-row workgroup with 2x2 tiles per wave was within 1.5 % of CH = 2 from 1024 boards up, at 256 VGPRs and 93
+//  spilled ones: dropped.)
 // 2-byte activations only: f32 rows (2 chunks) would need 128 KiB besides the weight ring.
 constexpr int R_LDS_W = 0;                    // 3 x 24 KiB
 // behind the ring: 2 x (ROWS x 128 B + a 128-byte zero row)
@@ -717,7 +717,8 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     typedef __bf16 T;
     typedef Mfma<T>::frag frag;
     constexpr int ROWS = 256 / CH;      // tower rows of this workgroup
-    constexpr int CB = CH == 1 ? 2 : 1;  // 32-cout blocks per consumer wave
+    static_assert(CH == 2 || CH == 4, "128 or 64 rows per workgroup");
+    constexpr int CB = 1;                // 32-cout blocks per consumer wave
     constexpr int NPB = CH == 4 ? 1 : 2; // 32-pixel blocks per consumer wave
     static_assert(!(BIG && CH == 4), "a 128-slot board needs 128 rows in one workgroup");
     constexpr int ZERO_OFF = LS ? 63 * 128 : ROWS * 128;    // the zero row of a buffer (padding pixels read it): behind its rows / slot 63
@@ -836,9 +837,9 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
 
     // ================================ consumer waves ================================
     const int r = lane & 31, h = lane >> 5;
-    const int rb = CH == 1 ? wave : CH == 2 ? wave >> 1 : 0;  // 64-row block of this wave
+    const int rb = CH == 2 ? wave >> 1 : 0;                   // 64-row block of this wave
     const int pb0 = CH == 4 ? wave >> 1 : 0;                  // first 32-pixel block of this wave inside its row block
-    const int coutb = CH == 1 ? 0 : (wave & 1) * 32;          // first output channel of this wave
+    const int coutb = (wave & 1) * 32;                        // first output channel of this wave
     const int pslot0 = BIG ? (rb & 1) * 64 : 0;
     const int board_lds = BIG ? (rb >> 1) * 16384 : rb * 8192;
     // Activation fragment addresses, relative to the input buffer: per (kernel row, tap column, pixel block) the
@@ -881,7 +882,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     }
 
     // fragments are read AHEAD stages before the MFMAs that use them; a stage is CB * NPB MFMAs
-    constexpr int AHEAD = CH == 1 ? 2 : CH == 2 ? 3 : 5, RING = AHEAD + 1;
+    constexpr int AHEAD = CH == 2 ? 3 : 5, RING = AHEAD + 1;
     int opaque = 0;
     frag wa[4];       // head conv weights of this lane's head channel row
     f32x4 hbias[4];   // head conv bias of the 16 head channels this lane's accumulator holds
@@ -1081,14 +1082,10 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     const int fin = (nlayers & 1) ? 0 : 1;  // the stem and every second conv of a block write buffer 0
     if (A.head_w) {
         // D[i][px] = sum_k W[i][k] * X[px][k]: A = head weights [32][64] (rows >= ocn are zero), B = tower rows.
-        // CH = 1: the wave covers its 64 rows (2 pixel blocks); CH = 2: the two waves of a row block take one each;
-        // CH = 4: the first wave of each pixel block takes it.
-        constexpr int HPB = CH == 1 ? 2 : 1;
+        // CH = 2: the two waves of a row block take one pixel block each; CH = 4: the first wave of each pixel block takes it.
         const int hwp = S * S;
-#pragma unroll
-        for (int pbi = 0; pbi < HPB; pbi++) {
-            if (CH == 4 && (wave & 1)) break;
-            const int pb = CH == 1 ? pbi : CH == 2 ? (wave & 1) : pb0;
+        if (!(CH == 4 && (wave & 1))) {
+            const int pb = CH == 2 ? (wave & 1) : pb0;
             const int row = rb * 64 + pb * 32 + r;
             f32x16 hacc;
 #pragma unroll
@@ -1147,12 +1144,9 @@ void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, bool layer_s
     if (ch == 4 && !big) {
         if (layer_steps && args.S * args.S <= 63) CATTUS_LAUNCH_T64_LS(4, false, true);
         else CATTUS_LAUNCH_T64(4, false);
-    } else if (ch == 2 || ch == 4) {
+    } else {
         if (big) CATTUS_LAUNCH_T64(2, true);
         else CATTUS_LAUNCH_T64(2, false);
-    } else {
-        if (big) CATTUS_LAUNCH_T64(1, true);
-        else CATTUS_LAUNCH_T64(1, false);
     }
 #undef CATTUS_LAUNCH_T64
 #undef CATTUS_LAUNCH_T64_LS
