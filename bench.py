@@ -227,6 +227,10 @@ def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, ma
         cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
                              first_game=rank, game_stride=world, seed=1, max_game_plies=max_game_plies,
                              **SELFPLAY_SETTINGS)  # random streams are per global game index
+        if world > 1:  # all ranks start the leg together: its rate is the sum of the ranks' evaluations over the slowest rank's time
+            import torch.distributed as dist
+
+            dist.barrier()
         t0 = time.perf_counter()
         res = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, games, keep_records=keep_records)
         play_s = time.perf_counter() - t0
