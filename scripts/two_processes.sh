@@ -1,5 +1,5 @@
 #!/bin/bash
-# one process, then two concurrent processes on the same GPU (6 search threads each)
+# 800-sim self-play: one process with 12 search threads, then two concurrent processes with 6 each, on the same GPU
 python scripts/e2e_selfplay.py 12 1536 800 1536 diverse plies=10 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('one process :', d['evals_per_s'], d['steady_evals_per_s'], d['batches'], d['seconds'], d['gpu_busy_frac'])"
 python scripts/e2e_selfplay.py 6 1536 800 1536 diverse plies=10 > /tmp/a.json &
 P1=$!
