@@ -380,9 +380,19 @@ int build(cattus_eval* e, const float* p) {
             for (size_t i = 0; i < v.size(); i++) hb[i] = f32_to_bf16(v[i]);
             return buf.upload(hb.data(), hb.size() * 2);
         };
+        // the FC weights go up in MFMA fragment order (kernels.h, HeadsMfma): a wave's operand of one k-step is one KiB
+        auto frag_order = [&](const std::vector<float>& v, uint32_t rows, uint32_t K) {
+            const uint32_t kstep = e->act == Act::F32 ? 8 : 16, half = kstep / 2;
+            std::vector<float> o(v.size());
+            for (uint32_t row = 0; row < rows; row++)
+                for (uint32_t k = 0; k < K; k++)
+                    o[((((size_t)(row >> 5) * (K / kstep) + k / kstep) * 2 + (k % kstep) / half) * 32 + (row & 31)) * half + k % half] =
+                        v[(size_t)row * K + k];
+            return o;
+        };
         if ((rc = upload_t(e->head_w, cw))) return rc;
-        if ((rc = upload_t(e->w1t, w1))) return rc;
-        if ((rc = upload_t(e->wpt, wp))) return rc;
+        if ((rc = upload_t(e->w1t, frag_order(w1, FC_HIDDEN, e->kvp)))) return rc;
+        if ((rc = upload_t(e->wpt, frag_order(wp, m32, e->kpp)))) return rc;
     } else {
         std::vector<float> w1t((size_t)kv * FC_HIDDEN), wpt((size_t)kp * d.moves);
         for (uint32_t j = 0; j < FC_HIDDEN; j++)
@@ -420,8 +430,9 @@ int build(cattus_eval* e, const float* p) {
         if ((rc = L.a.alloc(bp_ * slots * FA * esz))) return rc;
         if ((rc = L.t.alloc(bp_ * slots * FA * esz))) return rc;
         if ((rc = L.y.alloc(bp_ * slots * FA * esz))) return rc;
-        if ((rc = L.hv.alloc(bp_ * (e->kvp + e->kpp) * esz))) return rc;
-        HIP_TRY(hipMemset(L.hv.p, 0, bp_ * (e->kvp + e->kpp) * esz));  // pad columns must read as zero
+        const size_t hv_bytes = (size_t)(e->tuned ? (bp_ + 31) / 32 * 32 : bp_) * (e->kvp + e->kpp) * esz;  // tuned: whole 32-leaf tiles
+        if ((rc = L.hv.alloc(hv_bytes))) return rc;
+        HIP_TRY(hipMemset(L.hv.p, 0, hv_bytes));  // pad columns (and leaves never written) must read as zero
         if ((rc = L.h1.alloc(bp_ * FC_HIDDEN * 4))) return rc;
         if ((rc = L.d_policy.alloc(B * d.moves * 4))) return rc;
         if ((rc = L.d_value.alloc(B * 4))) return rc;
@@ -460,7 +471,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             ta.planes = d_planes, ta.layers = e->t64_layers.as<Tower64Layer>(), ta.out = nullptr;
             ta.n = n, ta.C = d.planes, ta.w64 = w64, ta.S = S, ta.nlayers = 1 + 2 * d.blocks;
             ta.head_w = e->head_w.p, ta.head_b = e->head_b.as<float>(), ta.hv = L.hv.p;
-            ta.hvs = e->kvp + e->kpp, ta.kvp = e->kvp, ta.vhc = d.vhc, ta.ocn = d.vhc + d.phc;
+            ta.hv_pol = (uint32_t)((e->bpad + 31) / 32 * 32) * e->kvp, ta.kvp = e->kvp, ta.kpp = e->kpp, ta.vhc = d.vhc, ta.ocn = d.vhc + d.phc;
             const uint32_t rows = nb * e->slots;
             // 128-row workgroups; for 64-slot boards one board per workgroup while that leaves no CU with two of them
             hipEvent_t s0 = ev(false), s1 = ev(true);
@@ -508,6 +519,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         hd.hw = hw, hd.vhc = d.vhc, hd.phc = d.phc, hd.kvp = e->kvp, hd.kpp = e->kpp, hd.M = d.moves;
         hd.w2 = e->w2.as<float>(), hd.b2 = e->b2.as<float>(), hd.value = d_value;
         hd.slots = e->slots;
+        hd.hv_leaves = (e->bpad + 31) / 32 * 32;
         launch_heads_mfma(e->act, e->tower64 ? nullptr : a, n, e->fpad, hd, st);
     } else {
         TowerView tv;

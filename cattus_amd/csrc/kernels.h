@@ -58,8 +58,8 @@ struct Tower64Args {
     // layout the head FC kernels read (HeadsMfma::hv)
     const void* head_w;   // [32][64] bf16, value rows first, rows >= ocn zero
     const float* head_b;  // [32]: entries >= ocn are not used
-    void* hv;             // [boards][hvs] bf16
-    uint32_t hvs, kvp, vhc, ocn;
+    void* hv;             // head activations in the fragment-packed layout of HeadsMfma::hv, bf16
+    uint32_t hv_pol, kvp, kpp, vhc, ocn;  // hv_pol: element offset of the policy part
 };
 // rows % 256 == 0; ch = 2: 128 rows per workgroup, ch = 4: one 64-slot board per workgroup (small batches; 128-slot
 // boards run as ch = 2).  layer_steps: with ch = 4 and boards of <= 63 pixels, one barrier per layer instead of three
@@ -76,8 +76,13 @@ void launch_conv3x3_generic(const float* in, const float* w, const float* bias, 
 // ---- K3-K5: heads on MFMA (tuned tower layout) ----------------------------------------------
 // All matrices are in the tower element type `act` with K contiguous and zero-padded:
 //   conv_w [32][F] (value rows, then policy rows, rest zero), conv_b [32] f32 (entries >= vhc+phc zero),
-//   hv [nb][kvp+kpp] (value part at 0, policy part at kvp; pad columns stay zero),
-//   w1 [128][kvp], b1 [128] f32, wp [round32(M)][kpp], bp [M] f32, policy [nb][M] f32;
+//   hv: value part [leaf][kvp] at element 0, policy part [leaf][kpp] at element hv_leaves * kvp, both stored in MFMA
+//   fragment order (below; pad columns stay zero), w1 [128][kvp] and wp [round32(M)][kpp] in the same order,
+//   b1 [128] f32, bp [M] f32, policy [nb][M] f32;
+//   fragment order of a [rows][K] matrix (rows padded to 32): element (row, k) lives at
+//     ((((row / 32) * (K / KSTEP) + k / KSTEP) * 2 + (k % KSTEP) / HALF) * 32 + row % 32) * HALF + k % HALF,
+//   KSTEP = 32 bytes of k, HALF = 16 bytes: the 64 lanes' 16-byte operand pieces of one 32-row tile and one MFMA k-step
+//   are one contiguous KiB, so a wave's fragment load is one fully coalesced instruction (no LDS staging, no barrier);
 //   h1 [nb][128] f32 is scratch of the stand-alone FC1 (the fused FC launch keeps the hidden units in LDS).
 //   kvp, kpp and F are multiples of 16 elements (the k walk reads whole 16-byte pieces).
 struct HeadsMfma {
@@ -93,6 +98,7 @@ struct HeadsMfma {
     const float *w2, *b2;  // value FC2 [128], [1]
     float* value;          // [nb], tanh applied
     uint32_t hw, vhc, phc, kvp, kpp, M;
+    uint32_t hv_leaves;    // leaf capacity of hv, a multiple of 32
     uint32_t slots;  // pixel slots per board of the tower (tower_slots)
 };
 void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, const HeadsMfma& hd, hipStream_t st);

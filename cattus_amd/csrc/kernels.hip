@@ -5,7 +5,7 @@
 //   K1  conv3x3_mfma_v2<T, HAS_RES, BIG, STEM>          3x3 conv + folded BN (+skip) + ReLU, one launch per layer (MFMA-bound)
 //   K1r tower64_lds<CH, BIG>                            whole tower of a <= 64-filter bf16 network in one launch, activations in LDS
 //   K1g conv3x3_generic                                 same arithmetic, any shape, SIMT f32 (checker; wide heads)
-//   K3  head_gemm<HEADCONV>, K4 + K5 head_fc_pair       1x1 head convs; value FC1 + FC2 + tanh and policy FC (MFMA)
+//   K3  head_conv, K4 + K5 head_fc_pair                 1x1 head convs; value FC1 + FC2 + tanh and policy FC (MFMA)
 //       head_conv1x1, value_fc1, value_fc2_tanh, policy_fc   the same on the generic path (SIMT f32)
 //
 // Arithmetic the kernels reproduce: ConvNetV1.forward in eval mode
@@ -187,6 +187,13 @@ struct Mfma<float> {
     }
 };
 
+// Element index of (row, k) of a [rows][K] matrix kept in MFMA fragment order (kernels.h, HeadsMfma).
+template <typename T>
+__host__ __device__ constexpr size_t frag_packed_index(uint32_t row, uint32_t k, uint32_t K) {
+    constexpr uint32_t KSTEP = 32 / sizeof(T), HALF = KSTEP / 2;
+    return ((((size_t)(row >> 5) * (K / KSTEP) + k / KSTEP) * 2 + (k % KSTEP) / HALF) * 32 + (row & 31)) * HALF + k % HALF;
+}
+
 // ---- diagnostic build only (-DCATTUS_STAMPS): per-wave cycle stamps of the v2 tower kernel ------
 #ifdef CATTUS_STAMPS
 __device__ unsigned long long g_stamps[512 * 8 * 8];
@@ -198,16 +205,7 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 #define STAMP_FLUSH(wave)                                                          \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)                               \
         for (int q_ = 0; q_ < 8; q_++) g_stamps[(blockIdx.x * 16 + (wave)) * 8 + q_] = st_[q_]
-__device__ unsigned long long g_hstamps[256 * 4 * 8];
-#define HSTAMP_PARAM , unsigned long long* st_
-#define HSTAMP_PASS , st_
-#define HSTAMP_FLUSH                                                                                  \
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256 && blockIdx.y * gridDim.x + blockIdx.x < 256)    \
-        for (int q_ = 0; q_ < 8; q_++) g_hstamps[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + q_] = st_[q_]
 #else
-#define HSTAMP_PARAM
-#define HSTAMP_PASS
-#define HSTAMP_FLUSH
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_RT(i)
@@ -616,9 +614,6 @@ static bool first_use_on_device(std::atomic<uint64_t>& mask) {
 #ifdef CATTUS_STAMPS
 extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(unsigned long long* out, size_t n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long));
-}
-extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_head_stamps(unsigned long long* out, size_t n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hstamps), n * sizeof(unsigned long long));
 }
 #endif
 
@@ -1077,7 +1072,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     }
     STAMP(2);
 
-    // ---- the two 1x1 head convs on the resident tower output (K3 fused; same MFMA order as head_gemm_tile) ----
+    // ---- the two 1x1 head convs on the resident tower output (K3 fused; same MFMA order as head_conv_tile) ----
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the loader waves have left: live waves only
     const int fin = (nlayers & 1) ? 0 : 1;  // the stem and every second conv of a block write buffer 0
     if (A.head_w) {
@@ -1098,14 +1093,15 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
             const uint32_t grow = (uint32_t)(row0 + row);
             const uint32_t bb = grow / SLOTS_PER_BOARD, p = grow % SLOTS_PER_BOARD;
             if ((int)p < hwp) {
-                T* hvrow = reinterpret_cast<T*>(A.hv) + (size_t)bb * A.hvs;
+                T* hvp = reinterpret_cast<T*>(A.hv);
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const uint32_t i = (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (i >= A.ocn) continue;
                     const float y = hacc[e] + hbias[e >> 2][e & 3];
-                    const uint32_t col = i < A.vhc ? i * hwp + p : A.kvp + (i - A.vhc) * hwp + p;
-                    hvrow[col] = (T)(y > 0.0f ? y : 0.0f);
+                    const size_t at = i < A.vhc ? frag_packed_index<T>(bb, i * hwp + p, A.kvp)
+                                                : A.hv_pol + frag_packed_index<T>(bb, (i - A.vhc) * hwp + p, A.kpp);
+                    hvp[at] = (T)(y > 0.0f ? y : 0.0f);
                 }
             }
         }
@@ -1202,22 +1198,21 @@ void launch_conv3x3_generic(const float* in, const float* w, const float* bias, 
 // kernels of the generic path, and in the CPU oracle alike.
 __host__ __device__ constexpr uint32_t kperm(uint32_t kk) { return (kk & ~7u) + ((kk & 1u) << 2) + ((kk & 7u) >> 1); }
 
-// ---- MFMA path: D[i][j] = sum_k P[i][k] * Q[j][k], P and Q row-major with K contiguous -----
-// One wave per 32x32 tile, fragments straight from global memory (the operands are small and
-// L2-resident); 4 waves of a block take 4 neighbouring j-tiles.  K % (128/sizeof(T)/4... ) see host.
-enum { EPI_HEADCONV = 0, EPI_FC1 = 1, EPI_POLICY = 2 };
+// ---- MFMA path: D[i][j] = sum_k P[i][k] * Q[j][k], K contiguous in both operands ------------
+enum { EPI_FC1 = 1, EPI_POLICY = 2 };
 
 struct HeadEpi {
     const float* bias;
     void* out;
-    uint32_t hw, vhc, ocn, hvs, kvp, M, slots;
+    uint32_t hw, vhc, ocn, hv_pol, kvp, kpp, M, slots;
 };
 
-// A block = 8 waves = a 32 (i) x 128 (j) strip: wave w < 4 owns j tile tj0 + w, waves 4-7 only stage operands.  The operands go through LDS in chunks of
-// 256 bytes per row, fetched with whole-line loads (16 lanes per row; a fragment read straight from memory touches 32
-// lines per instruction and uses a quarter of each -- the heads were bound by that, not by bytes), HG_DEPTH chunks
-// ahead in registers.  The MFMA order over k is
-// unchanged, so results are bit for bit those of the direct-load version.
+// ---- K3: the two 1x1 head convs as one GEMM, P = head weights [32][F], Q = tower rows [rows][F] (row-major) ----
+// A block = 8 waves = a 32 (i) x 128 (j) strip: wave w < 4 owns j tile tj0 + w, waves 4-7 only stage operands.  The
+// tower rows are what the conv kernel wrote, so the operands go through LDS in chunks of 256 bytes per row, fetched
+// with whole-line loads (16 lanes per row; a fragment read straight from a row-major matrix touches 32 lines per
+// instruction and uses a quarter of each: 18.9 us against 6.8 us for this launch, profiles/r02_experiments.txt),
+// HG_DEPTH chunks ahead in registers.  The epilogue writes hv in fragment order for the FC launch.
 constexpr int HG_ROWB = 256;                    // operand bytes per row and chunk: 128 bf16 / 64 f32 = 8 MFMA stages
 constexpr int HG_PITCH = HG_ROWB + 16;          // LDS row pitch: ds_read_b128 down a column of rows is conflict-free
 constexpr int HG_LDS = (32 + 128) * HG_PITCH;   // P rows 0..31, Q rows 32..159
@@ -1226,10 +1221,10 @@ constexpr int HG_PIECES = (32 + 128) * (HG_ROWB / 16) / HG_THREADS;  // 16-byte 
 constexpr int HG_DEPTH = 3;                     // chunks in flight per thread (registers)
 constexpr int HG_GROUP = 8;                     // chunks per straight-line group (1024 bf16 / 512 f32 k)
 
-template <typename T, int EPI>
-__device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t ldp, uint32_t I, const T* __restrict__ Q,
+template <typename T>
+__device__ __forceinline__ void head_conv_tile(const T* __restrict__ P, uint32_t ldp, uint32_t I, const T* __restrict__ Q,
                                                uint32_t ldq, uint32_t J, uint32_t K, const HeadEpi& ep, uint32_t bx,
-                                               uint32_t by, char* lds, float* stage HSTAMP_PARAM) {
+                                               uint32_t by, char* lds) {
     typedef typename Mfma<T>::frag frag;
     constexpr uint32_t KSTEP = 32 / sizeof(T);       // k per MFMA stage: 16 (bf16) or 8 (f32)
     constexpr uint32_t KCH = HG_ROWB / sizeof(T);    // k per chunk
@@ -1272,14 +1267,9 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
     };
     // epilogue operands requested now, so that their round trip is not paid after the last MFMA
     const uint32_t j = j0 + r;
-    float bias_j = 0.0f;
     f32x4 bias_i[4];
-    if constexpr (EPI == EPI_HEADCONV) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) bias_i[g] = *reinterpret_cast<const f32x4*>(ep.bias + 8 * g + 4 * h);  // 32 entries (padded)
-    } else {
-        bias_j = ep.bias[min(j, J - 1)];
-    }
+    for (int g = 0; g < 4; g++) bias_i[g] = *reinterpret_cast<const f32x4*>(ep.bias + 8 * g + 4 * h);  // 32 entries (padded)
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.0f;
@@ -1295,12 +1285,9 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
         for (int q = 0; q < HG_GROUP; q++) {
             const uint32_t c = g0 + q;
             if (c >= nchunks) break;
-            if (c == 1) STAMP(1);
             put(q % HG_DEPTH, c);
-            if (c == 1) STAMP(2);
             __syncthreads();
             if (q + HG_DEPTH < HG_GROUP) fetch(q % HG_DEPTH, c + HG_DEPTH);
-            if (c == 1) STAMP(3);
             if (active) {
                 const uint32_t left = K - c * KCH;
                 if (left >= KCH) {  // whole chunk: every fragment read is issued before the first MFMA needs one
@@ -1319,28 +1306,83 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
                             Mfma<T>::mac(*reinterpret_cast<const frag*>(arow + u * 32), *reinterpret_cast<const frag*>(brow + u * 32), acc);
                 }
             }
-            if (c == 1) STAMP(4);
             __syncthreads();
         }
     }
-    STAMP(5);
     if (!active) return;
     if (j >= J) return;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const uint32_t i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (i >= I) continue;
-        if constexpr (EPI == EPI_HEADCONV) {
-            // i = head channel (value rows first), j = tower row b*64 + p
-            const uint32_t bb = j / ep.slots, p = j % ep.slots;
-            if (i >= ep.ocn || p >= ep.hw) continue;
-            const float y = acc[e] + bias_i[e >> 2][e & 3];
-            const uint32_t col = i < ep.vhc ? i * ep.hw + p : ep.kvp + (i - ep.vhc) * ep.hw + p;
-            reinterpret_cast<T*>(ep.out)[(size_t)bb * ep.hvs + col] = (T)(y > 0.0f ? y : 0.0f);
-        } else if constexpr (EPI == EPI_FC1) {
+        // i = head channel (value rows first), j = tower row b*slots + p
+        const uint32_t bb = j / ep.slots, p = j % ep.slots;
+        if (i >= ep.ocn || p >= ep.hw) continue;
+        const float y = acc[e] + bias_i[e >> 2][e & 3];
+        const size_t at = i < ep.vhc ? frag_packed_index<T>(bb, i * ep.hw + p, ep.kvp)
+                                     : ep.hv_pol + frag_packed_index<T>(bb, (i - ep.vhc) * ep.hw + p, ep.kpp);
+        reinterpret_cast<T*>(ep.out)[at] = (T)(y > 0.0f ? y : 0.0f);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(HG_THREADS) head_conv_kernel(const T* __restrict__ P, uint32_t ldp, uint32_t I,
+                                                               const T* __restrict__ Q, uint32_t ldq, uint32_t J, uint32_t K,
+                                                               HeadEpi ep) {
+    __shared__ __attribute__((aligned(16))) char hg_lds[HG_LDS];
+    head_conv_tile<T>(P, ldp, I, Q, ldq, J, K, ep, blockIdx.x, blockIdx.y, hg_lds);
+}
+
+// ---- K4 + K5: the two FC layers on fragment-packed operands ------------------------------------
+// D[i][j] = sum_k P[i][k] * Q[j][k] with P (head activations, leaves) and Q (weights) both stored in MFMA fragment
+// order (kernels.h): a wave's operand for k-step u is one contiguous KiB, so it is read straight into registers with
+// one coalesced load per operand -- no LDS staging, no barrier -- HF_AHEAD steps ahead in a register ring.  The walk is
+// unrolled in straight-line groups of HF_GROUP steps with unconditional loads (a step beyond K re-reads the last one
+// and its MFMA is skipped): with loads in flight around a loop's back edge, or under a branch, the compiler waits for
+// all of them; here it counts.  One wave per 32x32 tile, 4 waves = 128 j per block; MFMA order over k as everywhere.
+constexpr int HF_AHEAD = 8;    // k-steps in flight per operand (2 x 8 x 4 VGPRs; 16 measured no better)
+constexpr int HF_GROUP = 32;   // k-steps per straight-line group (512 bf16 / 256 f32 k); loads of a group's unused tail are issued all the same
+template <typename T, int EPI>
+__device__ __forceinline__ void head_fc_tile_packed(const T* __restrict__ P, uint32_t I, const T* __restrict__ Q, uint32_t J,
+                                                    uint32_t K, const HeadEpi& ep, uint32_t bx, uint32_t by, float* stage) {
+    typedef typename Mfma<T>::frag frag;
+    constexpr uint32_t KSTEP = 32 / sizeof(T);  // k per MFMA stage: 16 (bf16) or 8 (f32)
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const uint32_t i0 = by * 32, jt = bx * 4 + wave, j0 = jt * 32;
+    if (j0 >= J) return;
+    const uint32_t nsteps = K / KSTEP;  // K is a multiple of 16 elements
+    const char* pa = reinterpret_cast<const char*>(P) + ((size_t)by * nsteps * 64 + lane) * 16;
+    const char* qb = reinterpret_cast<const char*>(Q) + ((size_t)jt * nsteps * 64 + lane) * 16;
+    const uint32_t j = j0 + r;
+    const float bias_j = ep.bias[min(j, J - 1)];  // requested now: its round trip is not paid after the last MFMA
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+    frag fa[HF_AHEAD], fb[HF_AHEAD];
+    auto fetch = [&](int slot, uint32_t u) {
+        const size_t off = (size_t)min(u, nsteps - 1) * 1024;
+        fa[slot] = *reinterpret_cast<const frag*>(pa + off);
+        fb[slot] = *reinterpret_cast<const frag*>(qb + off);
+    };
+    for (uint32_t u0 = 0; u0 < nsteps; u0 += HF_GROUP) {
+        const uint32_t left = nsteps - u0;  // > 0
+#pragma unroll
+        for (int s = 0; s < HF_AHEAD; s++) fetch(s, u0 + s);
+#pragma unroll
+        for (int q = 0; q < HF_GROUP; q++) {
+            if ((uint32_t)q < left) Mfma<T>::mac(fa[q % HF_AHEAD], fb[q % HF_AHEAD], acc);
+            if (q + HF_AHEAD < HF_GROUP) fetch(q % HF_AHEAD, u0 + q + HF_AHEAD);
+        }
+    }
+    if (j >= J) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const uint32_t i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i >= I) continue;
+        if constexpr (EPI == EPI_FC1) {
             const float y = acc[e] + bias_j;
-            if (stage) stage[(i - i0) * 129 + j] = y > 0.0f ? y : 0.0f;  // [32 leaves][128 hidden], padded rows
-            else reinterpret_cast<float*>(ep.out)[(size_t)i * 128 + j] = y > 0.0f ? y : 0.0f;
+            stage[(i - i0) * 129 + j] = y > 0.0f ? y : 0.0f;  // [32 leaves][128 hidden], padded rows
         } else {
             float y = acc[e] + bias_j;
             // non-finite logits -> f32::MIN (reference: engine/src/net/mod.rs:56-61)
@@ -1350,19 +1392,10 @@ __device__ __forceinline__ void head_gemm_tile(const T* __restrict__ P, uint32_t
     }
 }
 
-template <typename T, int EPI>
-__global__ void __launch_bounds__(HG_THREADS) head_gemm_kernel(const T* __restrict__ P, uint32_t ldp, uint32_t I,
-                                                        const T* __restrict__ Q, uint32_t ldq, uint32_t J, uint32_t K,
-                                                        HeadEpi ep) {
-    __shared__ __attribute__((aligned(16))) char hg_lds[HG_LDS];
-    STAMP_DECL;
-    head_gemm_tile<T, EPI>(P, ldp, I, Q, ldq, J, K, ep, blockIdx.x, blockIdx.y, hg_lds, nullptr HSTAMP_PASS);
-}
-
 // Value FC1 and policy FC read the same head activations and do not depend on each other: one launch, block column 0
 // does FC1 (128 hidden units = one strip), the others the policy FC (same tile code, same arithmetic).  What the first
 // loads need travels as plain kernel arguments (preloaded into SGPRs with the wave); the rest, in the struct, is
-// fetched by a scalar load that nothing waits on until the first LDS write.
+// fetched by a scalar load that nothing waits on until the epilogue.
 struct HeadFcTail {
     HeadEpi ep1, ep2;
     const float *w2, *b2;
@@ -1370,18 +1403,14 @@ struct HeadFcTail {
 };
 __device__ __forceinline__ float tanh_exact(float x);
 template <typename T>
-__global__ void __launch_bounds__(HG_THREADS) head_fc_pair_kernel(const T* __restrict__ p1, const T* __restrict__ q1,
-                                                           const T* __restrict__ p2, const T* __restrict__ q2, uint32_t ldp,
-                                                           uint32_t I, uint32_t ldq1, uint32_t K1, uint32_t ldq2, uint32_t J2,
-                                                           uint32_t K2, HeadFcTail a) {
-    __shared__ __attribute__((aligned(16))) char hg_lds[HG_LDS];
-    STAMP_DECL;
-    STAMP(0);
+__global__ void __launch_bounds__(256) head_fc_pair_kernel(const T* __restrict__ p1, const T* __restrict__ q1,
+                                                           const T* __restrict__ p2, const T* __restrict__ q2, uint32_t I,
+                                                           uint32_t K1, uint32_t J2, uint32_t K2, HeadFcTail a) {
     if (blockIdx.x == 0) {
         // The block's four waves hold all 128 hidden units of 32 leaves: stage them in LDS and finish the
         // value head here (FC2 + tanh, the fmaf chain of value_fc2_tanh_kernel), saving a launch.
         __shared__ float h1s[32 * 129];
-        head_gemm_tile<T, EPI_FC1>(p1, ldp, I, q1, ldq1, 128, K1, a.ep1, 0, blockIdx.y, hg_lds, h1s HSTAMP_PASS);
+        head_fc_tile_packed<T, EPI_FC1>(p1, I, q1, 128, K1, a.ep1, 0, blockIdx.y, h1s);
         __syncthreads();
         const uint32_t leaf = blockIdx.y * 32 + threadIdx.x;
         if (threadIdx.x < 32 && leaf < I) {
@@ -1396,35 +1425,30 @@ __global__ void __launch_bounds__(HG_THREADS) head_fc_pair_kernel(const T* __res
             }
             a.value[leaf] = tanh_exact(acc + a.b2[0]);
         }
-        STAMP(6);
     } else {
-        head_gemm_tile<T, EPI_POLICY>(p2, ldp, I, q2, ldq2, J2, K2, a.ep2, blockIdx.x - 1, blockIdx.y, hg_lds, nullptr HSTAMP_PASS);
-        STAMP(6);
+        head_fc_tile_packed<T, EPI_POLICY>(p2, I, q2, J2, K2, a.ep2, blockIdx.x - 1, blockIdx.y, nullptr);
     }
-    HSTAMP_FLUSH;
 }
 
-template <int EPI>
-static void launch_head_gemm(Act act, const void* P, uint32_t ldp, uint32_t I, const void* Q, uint32_t ldq, uint32_t J,
+static void launch_head_conv(Act act, const void* P, uint32_t ldp, uint32_t I, const void* Q, uint32_t ldq, uint32_t J,
                              uint32_t K, const HeadEpi& ep, hipStream_t st) {
     if (!I || !J) return;
     const dim3 grid(((J + 31) / 32 + 3) / 4, (I + 31) / 32), block(HG_THREADS);
     if (act == Act::BF16)
-        hipLaunchKernelGGL((head_gemm_kernel<__bf16, EPI>), grid, block, 0, st, (const __bf16*)P, ldp, I, (const __bf16*)Q, ldq,
-                           J, K, ep);
+        hipLaunchKernelGGL(head_conv_kernel<__bf16>, grid, block, 0, st, (const __bf16*)P, ldp, I, (const __bf16*)Q, ldq, J, K, ep);
     else
-        hipLaunchKernelGGL((head_gemm_kernel<float, EPI>), grid, block, 0, st, (const float*)P, ldp, I, (const float*)Q, ldq, J,
-                           K, ep);
+        hipLaunchKernelGGL(head_conv_kernel<float>, grid, block, 0, st, (const float*)P, ldp, I, (const float*)Q, ldq, J, K, ep);
 }
 
 void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, const HeadsMfma& hd, hipStream_t st) {
     HeadEpi ep{};
-    ep.hw = hd.hw, ep.vhc = hd.vhc, ep.ocn = hd.vhc + hd.phc, ep.hvs = hd.kvp + hd.kpp, ep.kvp = hd.kvp, ep.M = hd.M;
+    ep.hw = hd.hw, ep.vhc = hd.vhc, ep.ocn = hd.vhc + hd.phc, ep.kvp = hd.kvp, ep.kpp = hd.kpp, ep.M = hd.M;
+    ep.hv_pol = hd.hv_leaves * hd.kvp;
     ep.slots = hd.slots;
     // K3: both 1x1 convs in one GEMM: i = head channel, j = tower row (tower == nullptr: hv was already written
-    // by the resident tower kernel, which fuses this step)
+    // by the resident tower kernel, which fuses this step); writes hv in fragment order
     ep.bias = hd.conv_b, ep.out = hd.hv;
-    if (tower) launch_head_gemm<EPI_HEADCONV>(act, hd.conv_w, F, 32, tower, F, nb * hd.slots, F, ep, st);
+    if (tower) launch_head_conv(act, hd.conv_w, F, 32, tower, F, nb * hd.slots, F, ep, st);
     // K4 + K5 in one launch: value FC1 (+ReLU): i = leaf, j = hidden unit; policy FC: i = leaf, j = move
     const size_t esz = act == Act::BF16 ? 2 : 4;
     if (!nb) return;
@@ -1432,14 +1456,14 @@ void launch_heads_mfma(Act act, const void* tower, uint32_t nb, uint32_t F, cons
     a.ep1 = ep, a.ep1.bias = hd.b1, a.ep1.out = hd.h1;
     a.ep2 = ep, a.ep2.bias = hd.bp, a.ep2.out = hd.policy;
     a.w2 = hd.w2, a.b2 = hd.b2, a.value = hd.value;
-    const void* p2 = (const char*)hd.hv + (size_t)hd.kvp * esz;
-    const dim3 grid(1 + ((hd.M + 31) / 32 + 3) / 4, (nb + 31) / 32), block(HG_THREADS);
+    const void* p2 = (const char*)hd.hv + (size_t)ep.hv_pol * esz;
+    const dim3 grid(1 + ((hd.M + 31) / 32 + 3) / 4, (nb + 31) / 32), block(256);
     if (act == Act::BF16)
         hipLaunchKernelGGL(head_fc_pair_kernel<__bf16>, grid, block, 0, st, (const __bf16*)hd.hv, (const __bf16*)hd.w1,
-                           (const __bf16*)p2, (const __bf16*)hd.wp, ep.hvs, nb, hd.kvp, hd.kvp, hd.kpp, hd.M, hd.kpp, a);
+                           (const __bf16*)p2, (const __bf16*)hd.wp, nb, hd.kvp, hd.M, hd.kpp, a);
     else
         hipLaunchKernelGGL(head_fc_pair_kernel<float>, grid, block, 0, st, (const float*)hd.hv, (const float*)hd.w1,
-                           (const float*)p2, (const float*)hd.wp, ep.hvs, nb, hd.kvp, hd.kvp, hd.kpp, hd.M, hd.kpp, a);
+                           (const float*)p2, (const float*)hd.wp, nb, hd.kvp, hd.M, hd.kpp, a);
 }
 
 // ---- SIMT path (generic tower layout, any shape), same term order ---------------------------
