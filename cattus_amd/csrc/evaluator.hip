@@ -235,6 +235,8 @@ struct cattus_eval {
     bool tower64 = false;
     DevBuf t64_layers;
     bool pack_separately = false;  // CATTUS_FUSED_STEM=0: plane pack as its own launch in front of the stem (A/B, tests)
+    int t64_force_ch = 0;          // CATTUS_T64_CH=2|4: workgroup shape of the resident tower (A/B runs, the row-split test)
+    bool t64_layer_steps = true;   // CATTUS_T64_LS=0: three barriers per layer in the one-board resident tower
     int device = 0;
 
     ConvLayer stem;
@@ -295,10 +297,40 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
         if ((rc = L.b.upload(f.b.data(), cout * sizeof(float)))) return rc;
         return L.w.upload(f.w.data(), f.w.size() * sizeof(float));
     }
+    L.cin = cin_pad;
+    if (e->act == Act::F16S) {
+        // Split precision (kernels.hip, K1s): a weight is the pair hi = f16(w'), lo = f16(w' - hi) of w' = w * 2^s, with
+        // s chosen per output channel so that the channel's largest |w'| lies in [2^10, 2^11): the lo halves of all but
+        // the channel's tiniest weights are then normal f16 numbers (22 significant bits per weight), nothing comes near
+        // the f16 range limit, and 2^-s -- applied to the f32 accumulator in the epilogue -- undoes the scale exactly.
+        // Rows are [hi: cin_pad | lo: cin_pad]; the bias buffer is [cout_pad biases | cout_pad inverse scales].
+        std::vector<float> b((size_t)2 * cout_pad, 0.0f);
+        memcpy(b.data(), f.b.data(), cout * sizeof(float));
+        std::vector<_Float16> w((size_t)9 * cout_pad * 2 * cin_pad, (_Float16)0.0f);
+        for (uint32_t co = 0; co < cout_pad; co++) {
+            float m = 0.0f;
+            if (co < cout)
+                for (uint32_t t = 0; t < 9; t++)
+                    for (uint32_t ci = 0; ci < cin; ci++) m = std::max(m, fabsf(f.w[((size_t)t * cout + co) * cin + ci]));
+            int sh = 0;
+            if (m > 0.0f && std::isfinite(m)) sh = std::min(100, std::max(-100, 10 - ilogbf(m)));
+            b[cout_pad + co] = ldexpf(1.0f, -sh);
+            if (co >= cout) continue;
+            for (uint32_t t = 0; t < 9; t++)
+                for (uint32_t ci = 0; ci < cin; ci++) {
+                    const float ws = ldexpf(f.w[((size_t)t * cout + co) * cin + ci], sh);
+                    const _Float16 hi = (_Float16)ws;
+                    const _Float16 lo = (_Float16)(ws - (float)hi);
+                    _Float16* row = &w[((size_t)t * cout_pad + co) * 2 * cin_pad];
+                    row[ci] = hi, row[cin_pad + ci] = lo;
+                }
+        }
+        if ((rc = L.b.upload(b.data(), b.size() * sizeof(float)))) return rc;
+        return L.w.upload(w.data(), w.size() * 2);
+    }
     std::vector<float> b(cout_pad, 0.0f);
     memcpy(b.data(), f.b.data(), cout * sizeof(float));
     if ((rc = L.b.upload(b.data(), b.size() * sizeof(float)))) return rc;
-    L.cin = cin_pad;
     if (e->act == Act::BF16) {
         std::vector<uint16_t> w((size_t)9 * cout_pad * cin_pad, 0);
         for (uint32_t t = 0; t < 9; t++)
@@ -374,15 +406,16 @@ int build(cattus_eval* e, const float* p) {
         for (uint32_t oc = 0; oc < ocn; oc++) memcpy(&cw[(size_t)oc * FP], &hw_w[(size_t)oc * F], (size_t)F * 4);
         for (uint32_t j = 0; j < FC_HIDDEN; j++) memcpy(&w1[(size_t)j * e->kvp], &fc1_w[(size_t)j * kv], kv * 4);
         for (uint32_t m = 0; m < d.moves; m++) memcpy(&wp[(size_t)m * e->kpp], &pfc_w[(size_t)m * kp], kp * 4);
+        const Act hact = head_act(e->act);  // the split tower's heads run in exact f32 on the last layer's f32 rows
         auto upload_t = [&](DevBuf& buf, const std::vector<float>& v) -> int {
-            if (e->act == Act::F32) return buf.upload(v.data(), v.size() * 4);
+            if (hact == Act::F32) return buf.upload(v.data(), v.size() * 4);
             std::vector<uint16_t> hb(v.size());
             for (size_t i = 0; i < v.size(); i++) hb[i] = f32_to_bf16(v[i]);
             return buf.upload(hb.data(), hb.size() * 2);
         };
         // the FC weights go up in MFMA fragment order (kernels.h, HeadsMfma): a wave's operand of one k-step is one KiB
         auto frag_order = [&](const std::vector<float>& v, uint32_t rows, uint32_t K) {
-            const uint32_t kstep = e->act == Act::F32 ? 8 : 16, half = kstep / 2;
+            const uint32_t kstep = hact == Act::F32 ? 8 : 16, half = kstep / 2;
             std::vector<float> o(v.size());
             for (uint32_t row = 0; row < rows; row++)
                 for (uint32_t k = 0; k < K; k++)
@@ -420,6 +453,7 @@ int build(cattus_eval* e, const float* p) {
     // activations
     const size_t bp_ = e->bpad, B = e->cfg.max_batch;
     const size_t esz = e->tuned ? (size_t)act_bytes(e->act) : 4;
+    const size_t hesz = e->tuned ? (size_t)act_bytes(head_act(e->act)) : 4;  // element of the head activations
     const size_t slots = e->tuned ? e->slots : hw;
     const size_t FA = e->tuned ? FP : F;  // channels of the tower buffers
     for (Lane& L : e->lanes) {
@@ -430,7 +464,7 @@ int build(cattus_eval* e, const float* p) {
         if ((rc = L.a.alloc(bp_ * slots * FA * esz))) return rc;
         if ((rc = L.t.alloc(bp_ * slots * FA * esz))) return rc;
         if ((rc = L.y.alloc(bp_ * slots * FA * esz))) return rc;
-        const size_t hv_bytes = (size_t)(e->tuned ? (bp_ + 31) / 32 * 32 : bp_) * (e->kvp + e->kpp) * esz;  // tuned: whole 32-leaf tiles
+        const size_t hv_bytes = (size_t)(e->tuned ? (bp_ + 31) / 32 * 32 : bp_) * (e->kvp + e->kpp) * hesz;  // tuned: whole 32-leaf tiles
         if ((rc = L.hv.alloc(hv_bytes))) return rc;
         HIP_TRY(hipMemset(L.hv.p, 0, hv_bytes));  // pad columns (and leaves never written) must read as zero
         if ((rc = L.h1.alloc(bp_ * FC_HIDDEN * 4))) return rc;
@@ -476,22 +510,24 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             // 128-row workgroups; for 64-slot boards one board per workgroup while that leaves no CU with two of them
             hipEvent_t s0 = ev(false), s1 = ev(true);
             int ch = e->slots == 64 && rows / 64 <= 256 ? 4 : 2;
-            if (const char* force = getenv("CATTUS_T64_CH")) ch = atoi(force) == 4 && e->slots == 64 ? 4 : 2;  // A/B runs
-            const bool layer_steps = !(getenv("CATTUS_T64_LS") && atoi(getenv("CATTUS_T64_LS")) == 0);
-            launch_tower64(ta, rows, ch, layer_steps, st, s0, s1);
+            if (e->t64_force_ch) ch = e->t64_force_ch == 4 && e->slots == 64 ? 4 : 2;  // A/B runs, the row-split test
+            launch_tower64(ta, rows, ch, e->t64_layer_steps, st, s0, s1);
         } else {
             // the stem conv expands the planes itself when they fit one 128-byte chunk (every game here); else K0 first
             const bool fused_stem = d.planes <= 32 && e->cpad0 == (uint32_t)act_kc(e->act) && !e->pack_separately;
             const StemInput stem_in{d_planes, n, d.planes, w64};
             if (!fused_stem) launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
             hipEvent_t s0 = ev(false), s1 = ev(true);
+            // the split tower hands its last layer to the f32 head kernels as plain f32 rows
+            const int last_flags = e->act == Act::F16S ? 1 : 0;
             launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
-                                fused_stem ? &stem_in : nullptr);
+                                fused_stem ? &stem_in : nullptr, d.blocks == 0 ? last_flags : 0);
             for (uint32_t i = 0; i < d.blocks; i++) {
                 s0 = ev(false), s1 = ev(true);
                 launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1);
                 s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1);
+                launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1, nullptr,
+                                    i + 1 == d.blocks ? last_flags : 0);
                 std::swap(a, y);
             }
         }
@@ -520,7 +556,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         hd.w2 = e->w2.as<float>(), hd.b2 = e->b2.as<float>(), hd.value = d_value;
         hd.slots = e->slots;
         hd.hv_leaves = (e->bpad + 31) / 32 * 32;
-        launch_heads_mfma(e->act, e->tower64 ? nullptr : a, n, e->fpad, hd, st);
+        launch_heads_mfma(head_act(e->act), e->tower64 ? nullptr : a, n, e->fpad, hd, st);
     } else {
         TowerView tv;
         tv.x = a, tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;
@@ -704,7 +740,8 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if ((uint64_t)cfg->plane_words * 64 < (uint64_t)d.board * d.board || cfg->plane_words > 2)
         return fail(CATTUS_E_INVALID, "plane_words %u cannot hold a %ux%u board", cfg->plane_words, d.board, d.board);
     if (d.planes * cfg->plane_words > 128) return fail(CATTUS_E_UNSUPPORTED, "more than 128 plane words per leaf");
-    if (cfg->dtype != CATTUS_DTYPE_F32 && cfg->dtype != CATTUS_DTYPE_BF16) return fail(CATTUS_E_INVALID, "unknown dtype %u", cfg->dtype);
+    if (cfg->dtype != CATTUS_DTYPE_F32 && cfg->dtype != CATTUS_DTYPE_BF16 && cfg->dtype != CATTUS_DTYPE_F16X2)
+        return fail(CATTUS_E_INVALID, "unknown dtype %u", cfg->dtype);
     if ((size_t)d.phc * d.board * d.board * 8 * 4 > 64 * 1024) return fail(CATTUS_E_UNSUPPORTED, "policy head too wide for the FC kernel");
 
     int ndev = 0;
@@ -713,9 +750,24 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
         return fail(CATTUS_E_DEVICE, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(herr));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(CATTUS_E_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
+    {
+        // the tower kernels' dynamic-LDS opt-in: once per device, before anything can be launched on it
+        static std::mutex prep_mu;
+        static uint64_t prepared = 0;
+        std::lock_guard<std::mutex> lk(prep_mu);
+        const uint64_t bit = 1ull << (cfg->device & 63);
+        if (!(prepared & bit)) {
+            const hipError_t perr = prepare_device();
+            if (perr != hipSuccess) return fail(CATTUS_E_DEVICE, "hipFuncSetAttribute failed: %s", hipGetErrorString(perr));
+            prepared |= bit;
+        }
+    }
+    // every environment switch is read here, once per evaluator: nothing on the evaluation path calls getenv
     const char* wait_mode = getenv("CATTUS_HIP_WAIT");
     set_conv_cb(getenv("CATTUS_CONV_CB") ? atoi(getenv("CATTUS_CONV_CB")) : 0);
     const char* fused_stem_env = getenv("CATTUS_FUSED_STEM");
+    const char* t64_ch_env = getenv("CATTUS_T64_CH");
+    const char* t64_ls_env = getenv("CATTUS_T64_LS");
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
     if (!e) return fail(CATTUS_E_NOMEM, "out of memory");
@@ -725,15 +777,22 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->device = cfg->device;
     e->wait_spin = !(wait_mode && strcmp(wait_mode, "block") == 0);
     e->pack_separately = fused_stem_env && fused_stem_env[0] == '0';
+    e->t64_force_ch = t64_ch_env ? atoi(t64_ch_env) : 0;
+    e->t64_layer_steps = !(t64_ls_env && atoi(t64_ls_env) == 0);
     e->hw = d.board * d.board;
     // The MFMA tower covers every board up to 11x11 and any filter count (channels are padded to 64 with zeros);
     // the two 1x1 head convs share one 32-row MFMA tile.  Wider heads take the generic f32 path (one thread
     // per output, same arithmetic order), which otherwise serves as a checker only (CATTUS_FORCE_GENERIC=1).
     const char* force_generic = getenv("CATTUS_FORCE_GENERIC");
     e->tuned = d.vhc + d.phc <= 32 && !(force_generic && force_generic[0] == '1');
-    e->act = cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16 : Act::F32;
-    if (!e->tuned && e->act == Act::BF16)
-        return fail(CATTUS_E_UNSUPPORTED, "bf16 needs the MFMA tower: value + policy head channels <= 32 (got %u + %u)", d.vhc, d.phc);
+    e->act = cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16 : cfg->dtype == CATTUS_DTYPE_F16X2 ? Act::F16S : Act::F32;
+    if (!e->tuned && e->act != Act::F32)
+        return fail(CATTUS_E_UNSUPPORTED, "bf16 / f16x2 need the MFMA tower: value + policy head channels <= 32 (got %u + %u)", d.vhc, d.phc);
+    if (e->act == Act::F16S) {
+        // the split tower's stem expands the planes itself (its input has no lo half); no separate plane pack exists for it
+        if (d.planes > 32) return fail(CATTUS_E_UNSUPPORTED, "f16x2 takes at most 32 input planes (got %u)", d.planes);
+        e->pack_separately = false;
+    }
     e->slots = tower_slots(d.board);
     e->fpad = e->tuned ? (d.filters + COUT_PER_WG - 1) / COUT_PER_WG * COUT_PER_WG : d.filters;
     const uint32_t bpw = e->tuned ? ROWS_PER_WG / e->slots : 1;

@@ -10,12 +10,19 @@ inline uint32_t tower_slots(uint32_t S) { return S <= 8 ? 64u : 128u; }
 constexpr int ROWS_PER_WG = 256; // tower rows per workgroup of the conv kernel: 4 boards of 64 slots, 2 of 128
 constexpr int COUT_PER_WG = 64;  // output channels per workgroup of the tower conv kernel
 
-// Activation element of the tuned tower: 2-byte bf16 or 4-byte f32.
-enum class Act : int { F32 = 0, BF16 = 1 };
+// Activation element of the tuned tower: 2-byte bf16, 4-byte f32, or a pair of f16 values (hi, lo) of 2 + 2 bytes
+// (the split-precision tower: a row is [hi: channels | lo: channels]).
+enum class Act : int { F32 = 0, BF16 = 1, F16S = 2 };
 
-inline int act_bytes(Act a) { return a == Act::BF16 ? 2 : 4; }
+inline int act_bytes(Act a) { return a == Act::BF16 ? 2 : 4; }  // bytes of one activation in HBM
 // Input channels consumed per pipeline stage: one 128-byte LDS row.
-inline int act_kc(Act a) { return 128 / act_bytes(a); }
+inline int act_kc(Act a) { return a == Act::F32 ? 32 : 64; }
+// Element type of the head kernels (K3-K5) for a tower of type `a`: the split tower's heads run in exact f32.
+inline Act head_act(Act a) { return a == Act::BF16 ? Act::BF16 : Act::F32; }
+
+// Sets the > 64 KiB dynamic-LDS attribute of every tower kernel variant on the current device; called once per device
+// from cattus_hip_create before the first launch.
+hipError_t prepare_device();
 
 // ---- K0: bitboard planes -> tensors -------------------------------------------------------
 // NHWC tower input [bpad][slots][cpad] (rows >= n, slots >= S*S and channels >= C are zero).
@@ -35,9 +42,13 @@ struct StemInput {
     const uint64_t* planes;  // [n][C][w64]
     uint32_t n, C, w64;
 };
+// Act::F16S (split precision): in / res / out rows are [hi: c | lo: c] f16, w rows [hi: cin | lo: cin] f16 pre-scaled per
+// output channel by a power of two, bias is [cout bias | cout inverse scales]; cin counts the channels of one half.
+// flags & 1 (F16S only): out is written as plain f32 [row][cout] (last tower layer, read by the f32 head kernels).
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
-                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const StemInput* stem = nullptr);
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const StemInput* stem = nullptr,
+                         int flags = 0);
 
 // Forces the conv kernel's tile (1: 256 rows x 32 couts, 2: 256 rows x 64 couts; 0: chosen by grid size).
 void set_conv_cb(int v);

@@ -25,6 +25,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -175,6 +176,15 @@ struct Mfma<__bf16> {
     }
 };
 
+// f16 operands (the split-precision tower: DESIGN.md section 3, K1s): same lane map and cycles as the bf16 form
+template <>
+struct Mfma<_Float16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ void mac(const frag& a, const frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
 template <>
 struct Mfma<float> {
     typedef f32x4 frag;
@@ -240,7 +250,7 @@ __device__ __forceinline__ void wait_vm_barrier() {
 }
 
 #ifndef CATTUS_NLOAD
-#define CATTUS_NLOAD 4  // loader waves per workgroup (4 or 8)
+#define CATTUS_NLOAD 4  // loader waves per workgroup (the kernels assert 4)
 #endif
 constexpr int NLOAD = CATTUS_NLOAD;
 constexpr int WPL = 24 / NLOAD;  // weight pieces per loader wave and step
@@ -263,13 +273,29 @@ struct StemPlanes<true> {
 //     (consumer wave: 1 x 2 tiles): twice the workgroups for the same layer, used while the full-size grid would
 //     leave more than half of the CUs empty (batches of <= 128 leaves on a 256-filter net).  Same MFMA shape and
 //     k order per output element, so the result does not depend on which of the two ran.
-template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2>
+// SPLIT (T = _Float16; K1s, the split-precision tower): every activation and every weight is a PAIR of f16 values,
+//     x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 significant bits), and a product is three MFMA terms,
+//     a_hi w_hi + a_lo w_hi + a_hi w_lo, accumulated in f32 (a_lo w_lo, 2^-22 of the product, is dropped).  Rows of
+//     `in` / `res` / `out` are [hi: c channels | lo: c channels], rows of `w` [hi: cin | lo: cin]; the k walk goes over
+//     VIRTUAL chunks: real chunk c gives (a_hi, w_hi), (a_lo, w_hi), (a_hi, w_lo), so the loop below, the LDS map and
+//     the MFMA count per step are those of the bf16 kernel with three times the chunks (the stem's planes are 0/1, so
+//     its a_lo is zero: two virtual chunks on the one expanded activation chunk).  Weights are pre-scaled per output
+//     channel by a power of two (so that their lo halves are normal f16 numbers); `bias` is followed by the cout
+//     inverse scales, applied (exactly) in the epilogue.  flags & 1: the output is written as plain f32 [row][cout]
+//     instead of a pair (the last tower layer, for the f32 head kernels).
+constexpr int CONV_OUT_F32 = 1;
+
+template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2, bool SPLIT = false>
 __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S, StemPlanes<STEM> sp) {
+                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S, int flags,
+                           StemPlanes<STEM> sp) {
+    static_assert(!SPLIT || sizeof(T) == 2, "split precision runs on 2-byte operands");
+    static_assert(NLOAD == 4, "the stem expansion, the 32-cout tile and the piece counts below assume four loader waves");
     constexpr int KC = 128 / (int)sizeof(T);
     constexpr int CPW = 32 * CB;          // output channels of this workgroup
     constexpr int WPLC = WPL * CB / 2;    // weight pieces per loader wave and step
+    constexpr int PARTS = SPLIT ? 2 : 1;  // hi | lo halves of a row
     typedef typename Mfma<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -290,9 +316,10 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
 
-    const int nch = cin / KC;
+    const int nch_real = cin / KC;                                       // 128-byte chunks of one half of a row
+    const int nch = SPLIT ? (STEM ? 2 : 3) * nch_real : nch_real;        // chunks the k walk visits (virtual ones with SPLIT)
     const int T_total = nch * 3;
-    const uint32_t row_bytes = (uint32_t)cin * sizeof(T);
+    const uint32_t row_bytes = (uint32_t)cin * sizeof(T) * PARTS;        // a row of `in` / `w`: [hi | lo] with SPLIT
 
     if (is_loader) {
         // ================================ loader waves ================================
@@ -322,13 +349,23 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
         auto issue_w = [&](int t) {  // weight slab of step t -> ring slot t % 3
             const int ch = t / 3, g = t - ch * 3;
-            const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)ch * 128;
+            int wch = ch;  // chunk of the weight rows: SPLIT walks (hi, hi, lo) per real chunk, the stem (hi, lo)
+            if constexpr (SPLIT && !STEM) {
+                const int c = ch / 3, j = ch - c * 3;
+                wch = c + (j == 2 ? nch_real : 0);
+            }
+            const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)wch * 128;
             char* dst = smem + V2_LDS_W + (t % 3) * V2_SLAB;
 #pragma unroll
             for (int i = 0; i < WPLC; i++) glds16(src + off_w[i], dst + dst_w[i]);
         };
         auto issue_a = [&](int ch, int g) {  // half g of activation chunk ch -> buffer ch & 1
-            const char* src = abase0 + (size_t)ch * 128;
+            int ach = ch;  // chunk of the activation rows: SPLIT walks (hi, lo, hi) per real chunk
+            if constexpr (SPLIT) {
+                const int c = ch / 3, j = ch - c * 3;
+                ach = c + (j == 1 ? nch_real : 0);
+            }
+            const char* src = abase0 + (size_t)ach * 128;
             char* dst = smem + V2_LDS_ACT + (ch & 1) * 32768;
 #pragma unroll
             for (int i = 0; i < APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
@@ -396,7 +433,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 issue_w(t + 2);
                 pending += WPLC;
             }
-            if (g < 2 && ch + 1 < nch) {
+            if (!STEM && g < 2 && ch + 1 < nch) {  // the stem has one activation chunk, expanded above
                 issue_a(ch + 1, g);
                 pending += APL;
             }
@@ -446,20 +483,24 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     // Epilogue operands that depend on nothing computed here are requested now, so their latency hides
     // under the main loop: the folded-BN bias of this lane's 8 cout quads, and (2-byte activations only,
     // for register budget) the skip-connection rows in the epilogue's (pixel row, 8 couts) layout.
-    f32x4 biasv[CB][4];
+    f32x4 biasv[CB][4], dsv[SPLIT ? CB : 1][4];
 #pragma unroll
     for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-        for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
+        for (int g = 0; g < 4; g++) {
+            biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
+            if constexpr (SPLIT) dsv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cb * 32 + g * 8 + h * 4);
+        }
     // epilogue store layout: a pixel row of the tile is CPW couts = LPR lanes x 8 couts; 64 / LPR rows per trip
     constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = 64 / RPT;
     const int prow = lane / LPR, cg = lane % LPR;
-    constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2;
-    T resv[EIT][8];
+    constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2 && !SPLIT;
+    const size_t orow = (size_t)cout * PARTS;  // elements per row of `res` / `out`
+    T resv[EIT][8 * PARTS];
     if (RES_EARLY) {
 #pragma unroll
         for (int i = 0; i < EIT; i++) {
-            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * (size_t)cout + cout0 + cg * 8;
+            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * orow + cout0 + cg * 8;
             *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
         }
     }
@@ -470,7 +511,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     constexpr int AHEAD = CB == 2 ? 2 : 3, RING = AHEAD + 1;
     int opaque = 0;
     for (int ch = 0; ch < nch; ch++) {
-        const int abase = V2_LDS_ACT + (ch & 1) * 32768 + board_lds;
+        const int abase = V2_LDS_ACT + (STEM ? 0 : (ch & 1) * 32768) + board_lds;
 #pragma unroll
         for (int g = 0; g < 3; g++) {
             // all fragment reads of the previous step have returned before the loaders may reuse its slab
@@ -543,8 +584,11 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         if (HAS_RES && !RES_EARLY) {
 #pragma unroll
             for (int i = 0; i < EIT; i++) {
-                const size_t off = (wrow0 + i * RPT + prow) * (size_t)cout + cout0 + cg * 8;
-                if (sizeof(T) == 2) {
+                const size_t off = (wrow0 + i * RPT + prow) * orow + cout0 + cg * 8;
+                if (SPLIT) {  // hi and lo halves of the row
+                    reinterpret_cast<f32x4*>(resv[i])[0] = *reinterpret_cast<const f32x4*>(res + off);
+                    reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(res + off + cout);
+                } else if (sizeof(T) == 2) {
                     *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
                 } else {
                     reinterpret_cast<f32x4*>(resv[i])[0] = reinterpret_cast<const f32x4*>(res + off)[0];
@@ -564,7 +608,11 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                     const f32x4 bv = biasv[cb][g];
                     f32x4 v;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
+                    for (int i = 0; i < 4; i++) {
+                        // SPLIT: the accumulator carries the weights' power-of-two scale; times its inverse is exact
+                        if constexpr (SPLIT) v[i] = acc[cb][pb][g * 4 + i] * dsv[cb][g][i] + bv[i];
+                        else v[i] = acc[cb][pb][g * 4 + i] + bv[i];
+                    }
                     const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
                     *reinterpret_cast<f32x4*>(smem + stage_row(pb * 32 + r) + slot * 16) = v;
                 }
@@ -575,12 +623,40 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (px & 7)) << 4));
             const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (px & 7)) << 4));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const size_t off = (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
+            const size_t off = (wrow0 + px) * orow + cout0 + cg * 8;
             if (HAS_RES) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = v[j] + (float)resv[i][j];
+                for (int j = 0; j < 8; j++) {
+                    // SPLIT: hi + lo is exact in f32 (lo is at most half an ulp of hi: 22 significant bits)
+                    if constexpr (SPLIT) v[j] = v[j] + ((float)resv[i][j] + (float)resv[i][8 + j]);
+                    else v[j] = v[j] + (float)resv[i][j];
+                }
             }
             const bool valid = pslot0 + px < S * S;
+            if constexpr (SPLIT) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    y[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                    if (!valid) y[j] = 0.0f;
+                }
+                if (flags & CONV_OUT_F32) {  // the tower's last layer: plain f32 rows for the head kernels
+                    float* of = reinterpret_cast<float*>(out) + (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
+                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y), reinterpret_cast<f32x4*>(of));
+                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y + 4), reinterpret_cast<f32x4*>(of) + 1);
+                } else {
+                    T hi[8], lo[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float yc = y[j] < 65504.0f ? y[j] : 65504.0f;  // saturate instead of overflowing to infinity
+                        hi[j] = (T)yc;
+                        lo[j] = (T)(yc - (float)hi[j]);
+                    }
+                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(hi), reinterpret_cast<f32x4*>(out + off));
+                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(lo), reinterpret_cast<f32x4*>(out + off + cout));
+                }
+                continue;
+            }
             T ov[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -603,14 +679,6 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     STAMP_FLUSH(wave);
 }
 
-// The opt-in for > 64 KiB of dynamic LDS is a per-device function attribute: set it once per device.
-static bool first_use_on_device(std::atomic<uint64_t>& mask) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const uint64_t bit = 1ull << (dev & 63);
-    return (mask.fetch_or(bit) & bit) == 0;
-}
-
 #ifdef CATTUS_STAMPS
 extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(unsigned long long* out, size_t n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long));
@@ -620,56 +688,65 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 int g_conv_cb = 0;  // 0: by grid size; 1 / 2: 32 / 64 couts per workgroup (CATTUS_CONV_CB, A/B runs and the equality test)
 void set_conv_cb(int v) { g_conv_cb = (v == 1 || v == 2) ? v : 0; }
 
+// Every conv variant that exists, with its opt-in for > 64 KiB of dynamic LDS (a per-device function attribute).
+// Called once per device from cattus_hip_create (under its lock), so that no launch ever races the attribute call.
+template <typename T, bool SPLIT>
+static hipError_t conv_attrs_for() {
+    hipError_t err = hipSuccess;
+    auto set = [&](const void* fn) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+    };
+#define CATTUS_ATTR_CB(CBV)                                                                                  \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, false, false, CBV, SPLIT>));         \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, true, false, false, CBV, SPLIT>));          \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, true, false, CBV, SPLIT>));          \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, true, true, false, CBV, SPLIT>));           \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, false, true, CBV, SPLIT>));          \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, true, true, CBV, SPLIT>));
+    CATTUS_ATTR_CB(1)
+    CATTUS_ATTR_CB(2)
+#undef CATTUS_ATTR_CB
+    return err;
+}
+
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st, hipEvent_t ev_start,
-                         hipEvent_t ev_stop, const StemInput* stem) {
+                         hipEvent_t ev_stop, const StemInput* stem, int flags) {
     const uint32_t slots = tower_slots(S);
     // 256 rows x 64 couts per workgroup; 256 rows x 32 couts while that grid would leave half of the CUs empty
     const uint32_t full_grid = (bpad * slots / ROWS_PER_WG) * (cout / COUT_PER_WG);
     int cb = full_grid <= 128 ? 1 : 2;
     if (g_conv_cb) cb = g_conv_cb;
     const dim3 grid(full_grid * (cb == 1 ? 2 : 1));
-#define CATTUS_LAUNCH_CONV2(T, R, BIG, CBV)                                                               \
-    do {                                                                                                  \
-        static std::atomic<uint64_t> attr_set{0};                                                         \
-        if (first_use_on_device(attr_set)) {                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
-        }                                                                                                 \
-        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                              (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{}); \
+#define CATTUS_LAUNCH_CONV2(T, R, BIG, CBV, SP)                                                           \
+    hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV, SP>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                          (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, flags, StemPlanes<false>{})
+#define CATTUS_LAUNCH_STEM(T, BIG, CBV, SP)                                                               \
+    hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV, SP>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                          (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, flags, \
+                          StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64})
+#define CATTUS_LAUNCH_CONV2_CB(T, CBV, SP)                            \
+    do {                                                              \
+        if (stem) {                                                   \
+            if (slots == 128) CATTUS_LAUNCH_STEM(T, true, CBV, SP);   \
+            else CATTUS_LAUNCH_STEM(T, false, CBV, SP);               \
+        } else if (slots == 128) {                                    \
+            if (res) CATTUS_LAUNCH_CONV2(T, true, true, CBV, SP);     \
+            else CATTUS_LAUNCH_CONV2(T, false, true, CBV, SP);        \
+        } else {                                                      \
+            if (res) CATTUS_LAUNCH_CONV2(T, true, false, CBV, SP);    \
+            else CATTUS_LAUNCH_CONV2(T, false, false, CBV, SP);       \
+        }                                                             \
     } while (0)
-#define CATTUS_LAUNCH_STEM(T, BIG, CBV)                                                                   \
-    do {                                                                                                  \
-        static std::atomic<uint64_t> attr_set{0};                                                         \
-        if (first_use_on_device(attr_set)) {                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);          \
-        }                                                                                                 \
-        hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                              (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
-                              StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64});               \
+#define CATTUS_LAUNCH_CONV2_T(T, SP)                  \
+    do {                                              \
+        if (cb == 1) CATTUS_LAUNCH_CONV2_CB(T, 1, SP); \
+        else CATTUS_LAUNCH_CONV2_CB(T, 2, SP);        \
     } while (0)
-#define CATTUS_LAUNCH_CONV2_CB(T, CBV)                            \
-    do {                                                          \
-        if (stem) {                                               \
-            if (slots == 128) CATTUS_LAUNCH_STEM(T, true, CBV);   \
-            else CATTUS_LAUNCH_STEM(T, false, CBV);               \
-        } else if (slots == 128) {                                \
-            if (res) CATTUS_LAUNCH_CONV2(T, true, true, CBV);     \
-            else CATTUS_LAUNCH_CONV2(T, false, true, CBV);        \
-        } else {                                                  \
-            if (res) CATTUS_LAUNCH_CONV2(T, true, false, CBV);    \
-            else CATTUS_LAUNCH_CONV2(T, false, false, CBV);       \
-        }                                                         \
-    } while (0)
-#define CATTUS_LAUNCH_CONV2_T(T)                  \
-    do {                                          \
-        if (cb == 1) CATTUS_LAUNCH_CONV2_CB(T, 1); \
-        else CATTUS_LAUNCH_CONV2_CB(T, 2);        \
-    } while (0)
-    if (act == Act::BF16) CATTUS_LAUNCH_CONV2_T(__bf16);
-    else CATTUS_LAUNCH_CONV2_T(float);
+    if (act == Act::BF16) CATTUS_LAUNCH_CONV2_T(__bf16, false);
+    else if (act == Act::F16S) CATTUS_LAUNCH_CONV2_T(_Float16, true);
+    else CATTUS_LAUNCH_CONV2_T(float, false);
 #undef CATTUS_LAUNCH_CONV2_T
 #undef CATTUS_LAUNCH_CONV2_CB
 #undef CATTUS_LAUNCH_STEM
@@ -707,6 +784,7 @@ constexpr int tower64_lds_bytes(int ch, bool ls) { return ls ? 6 * V2_SLAB + 2 *
 
 template <int CH, bool BIG, bool LS = false>
 __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
+    static_assert(NLOAD == 4, "512 threads: four consumer and four loader waves");
     static_assert(!LS || CH == 4, "layer steps: one board per workgroup only");
     constexpr int R_LDS_ACT = (LS ? 6 : 3) * V2_SLAB;
     typedef __bf16 T;
@@ -1127,15 +1205,8 @@ void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, bool layer_s
                     hipEvent_t ev_stop) {
     const bool big = tower_slots(args.S) == 128;
 #define CATTUS_LAUNCH_T64_LS(CH, BIG, LS)                                                                       \
-    do {                                                                                                        \
-        static std::atomic<uint64_t> attr_set{0};                                                               \
-        if (first_use_on_device(attr_set)) {                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower64_lds_kernel<CH, BIG, LS>),         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, tower64_lds_bytes(CH, LS));   \
-        }                                                                                                       \
-        hipExtLaunchKernelGGL((tower64_lds_kernel<CH, BIG, LS>), dim3(rows / (256 / CH)), dim3(512), tower64_lds_bytes(CH, LS), st, \
-                              ev_start, ev_stop, 0, args);                                                      \
-    } while (0)
+    hipExtLaunchKernelGGL((tower64_lds_kernel<CH, BIG, LS>), dim3(rows / (256 / CH)), dim3(512), tower64_lds_bytes(CH, LS), st, \
+                          ev_start, ev_stop, 0, args)
 #define CATTUS_LAUNCH_T64(CH, BIG) CATTUS_LAUNCH_T64_LS(CH, BIG, false)
     if (ch == 4 && !big) {
         if (layer_steps && args.S * args.S <= 63) CATTUS_LAUNCH_T64_LS(4, false, true);
@@ -1146,6 +1217,26 @@ void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, bool layer_s
     }
 #undef CATTUS_LAUNCH_T64
 #undef CATTUS_LAUNCH_T64_LS
+}
+
+// The opt-in for > 64 KiB of dynamic LDS is a per-device function attribute.  Every variant gets it here, once per
+// device, before anything is launched on that device: cattus_hip_create calls this under a lock, so two evaluation
+// threads can never meet a variant whose attribute call is still on its way.
+hipError_t prepare_device() {
+    hipError_t err = conv_attrs_for<__bf16, false>();
+    hipError_t e2 = conv_attrs_for<float, false>();
+    if (err == hipSuccess) err = e2;
+    e2 = conv_attrs_for<_Float16, true>();
+    if (err == hipSuccess) err = e2;
+    auto set = [&](const void* fn, int bytes) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+    };
+    set(reinterpret_cast<const void*>(&tower64_lds_kernel<4, false, true>), tower64_lds_bytes(4, true));
+    set(reinterpret_cast<const void*>(&tower64_lds_kernel<4, false, false>), tower64_lds_bytes(4, false));
+    set(reinterpret_cast<const void*>(&tower64_lds_kernel<2, true, false>), tower64_lds_bytes(2, false));
+    set(reinterpret_cast<const void*>(&tower64_lds_kernel<2, false, false>), tower64_lds_bytes(2, false));
+    return err;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -39,7 +39,12 @@ typedef enum cattus_status {
 
 typedef enum cattus_dtype {
     CATTUS_DTYPE_F32 = 0,  /* exact f32 MFMA, bit-identical to the CPU oracle's summation order */
-    CATTUS_DTYPE_BF16 = 1, /* bf16 operands / f32 accumulate MFMA tower (throughput mode) */
+    CATTUS_DTYPE_BF16 = 1, /* bf16 operands / f32 accumulate MFMA tower (throughput mode, 8 significant bits) */
+    /* Split precision: every activation and weight of the conv tower is a pair of f16 values (hi + lo, 22 significant
+     * bits), a product is three f16 MFMA terms accumulated in f32, the heads run in exact f32.  Error against a
+     * float64 run of the network is that of an f32 runtime (the reference's cross-runtime tolerance,
+     * training/tests/test_net_output.py:28-33), at about a third of the bf16 tower's rate. */
+    CATTUS_DTYPE_F16X2 = 2,
 } cattus_dtype;
 
 /* Replaces the reference's InferenceConfig + batch_size (engine/src/net/model.rs:17-25,
