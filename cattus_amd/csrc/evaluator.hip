@@ -303,7 +303,8 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
         // s chosen per output channel so that the channel's largest |w'| lies in [2^10, 2^11): the lo halves of all but
         // the channel's tiniest weights are then normal f16 numbers (22 significant bits per weight), nothing comes near
         // the f16 range limit, and 2^-s -- applied to the f32 accumulator in the epilogue -- undoes the scale exactly.
-        // Rows are [hi: cin_pad | lo: cin_pad]; the bias buffer is [cout_pad biases | cout_pad inverse scales].
+        // Rows are [hi of 32 input channels | lo of the same 32] per 128 bytes; the bias buffer is [cout_pad biases |
+        // cout_pad inverse scales].
         std::vector<float> b((size_t)2 * cout_pad, 0.0f);
         memcpy(b.data(), f.b.data(), cout * sizeof(float));
         std::vector<_Float16> w((size_t)9 * cout_pad * 2 * cin_pad, (_Float16)0.0f);
@@ -321,8 +322,8 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
                     const float ws = ldexpf(f.w[((size_t)t * cout + co) * cin + ci], sh);
                     const _Float16 hi = (_Float16)ws;
                     const _Float16 lo = (_Float16)(ws - (float)hi);
-                    _Float16* row = &w[((size_t)t * cout_pad + co) * 2 * cin_pad];
-                    row[ci] = hi, row[cin_pad + ci] = lo;
+                    _Float16* row = &w[((size_t)t * cout_pad + co) * 2 * cin_pad + (size_t)(ci >> 5) * 64 + (ci & 31)];
+                    row[0] = hi, row[32] = lo;
                 }
         }
         if ((rc = L.b.upload(b.data(), b.size() * sizeof(float)))) return rc;

@@ -394,6 +394,28 @@ SP_API int64_t cattus_sp_trace_game(int game, const cattus_sp_config* c, cattus_
     return cattus_sp_trace_game_ex(game, c, net, ctx, max_plies, nullptr, 0, 0, out, cap);
 }
 
+// ---- known-answer hooks for the stochastic paths (the very functions the search calls) ----
+SP_API int cattus_sp_test_dirichlet(uint64_t seed, float alpha, uint32_t k, uint32_t draws, double* out) {
+    if (!out || k < 1 || !(alpha > 0)) return -1;
+    Rng rng(seed);
+    std::vector<double> g;
+    for (uint32_t d = 0; d < draws; d++) {
+        if (!sample_dirichlet(rng, alpha, k, g)) std::fill(g.begin(), g.end(), 0.0);
+        std::copy(g.begin(), g.end(), out + (size_t)d * k);
+    }
+    return 0;
+}
+
+SP_API int cattus_sp_test_temperature_choice(uint64_t seed, const float* probs, uint32_t k, float temperature, uint32_t draws,
+                                             uint32_t* counts) {
+    if (!probs || !counts || k < 1 || !(temperature > 0)) return -1;
+    Rng rng(seed);
+    std::vector<float> w;
+    std::fill(counts, counts + k, 0u);
+    for (uint32_t d = 0; d < draws; d++) counts[sample_with_temperature(rng, probs, k, temperature, w)]++;
+    return 0;
+}
+
 SP_API int cattus_sp_play_moves(int game, const uint16_t* moves, uint32_t n, uint32_t* plies_played) {
     int status = -100;
     dispatch(game, [&](auto g) -> int {

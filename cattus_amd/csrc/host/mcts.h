@@ -68,6 +68,38 @@ struct Rng {
     }
 };
 
+// One draw from the symmetric Dirichlet distribution Dir(alpha, ..., alpha) over k categories: k Gamma(alpha, 1) variates
+// over their sum (what util/dirichlet.rs:226-352 samples for mcts/mod.rs:435-441).  Returns false when the sum is not
+// positive (every variate underflowed: the reference redraws on non-finite noise; here the priors stay as they are).
+inline bool sample_dirichlet(Rng& rng, double alpha, size_t k, std::vector<double>& out) {
+    out.resize(k);
+    double sum = 0;
+    for (auto& x : out) {
+        x = rng.gamma(alpha);
+        sum += x;
+    }
+    if (!(sum > 0)) return false;
+    for (auto& x : out) x /= sum;
+    return true;
+}
+
+// Index drawn with probability proportional to p_i^(1/t) (mcts/mod.rs:403-415: powf, f32 sum, WeightedIndex).
+inline size_t sample_with_temperature(Rng& rng, const float* probs, size_t n, float t, std::vector<float>& w) {
+    w.resize(n);
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        w[i] = std::pow(probs[i], 1.0f / t);
+        sum += w[i];
+    }
+    const double u = rng.uniform() * (double)sum;
+    double accw = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        accw += w[i];
+        if (u < accw) return i;
+    }
+    return n - 1;
+}
+
 // TemperaturePolicy (mcts/mod.rs:456-489)
 struct TemperaturePolicy {
     std::vector<std::pair<size_t, float>> scheduled;  // strictly increasing thresholds
@@ -219,22 +251,9 @@ class MctsPlayer {
             out = probs[best].first;
             return true;
         }
-        std::vector<float> w(probs.size());
-        float sum = 0.0f;
-        for (size_t i = 0; i < probs.size(); i++) {
-            w[i] = std::pow(probs[i].second, 1.0f / t);
-            sum += w[i];
-        }
-        double u = rng_.uniform() * (double)sum, accw = 0.0;
-        size_t pick = probs.size() - 1;
-        for (size_t i = 0; i < probs.size(); i++) {
-            accw += w[i];
-            if (u < accw) {
-                pick = i;
-                break;
-            }
-        }
-        out = probs[pick].first;
+        std::vector<float> p(probs.size()), w;
+        for (size_t i = 0; i < probs.size(); i++) p[i] = probs[i].second;
+        out = probs[sample_with_temperature(rng_, p.data(), p.size(), t, w)].first;
         return true;
     }
 
@@ -441,18 +460,13 @@ class MctsPlayer {
         if (params_.prior_noise_alpha == 0.0f || params_.prior_noise_epsilon == 0.0f) return;
         const Node& nd = nodes_[node_id];
         if (nd.count < 2) return;
-        std::vector<double> g(nd.count);
-        double sum = 0;
-        for (auto& x : g) {
-            x = rng_.gamma(params_.prior_noise_alpha);
-            sum += x;
-        }
-        if (!(sum > 0)) return;
+        std::vector<double> g;
+        if (!sample_dirichlet(rng_, params_.prior_noise_alpha, nd.count, g)) return;
         const float eps = params_.prior_noise_epsilon;
         uint32_t k = 0;
         for (uint32_t i = nd.count; i-- > 0; k++) {  // edges() order
             Edge& e = edges_[nd.first + i];
-            e.init_score = (1.0f - eps) * e.init_score + eps * (float)(g[k] / sum);
+            e.init_score = (1.0f - eps) * e.init_score + eps * (float)g[k];
         }
     }
 

@@ -11,12 +11,12 @@ constexpr int ROWS_PER_WG = 256; // tower rows per workgroup of the conv kernel:
 constexpr int COUT_PER_WG = 64;  // output channels per workgroup of the tower conv kernel
 
 // Activation element of the tuned tower: 2-byte bf16, 4-byte f32, or a pair of f16 values (hi, lo) of 2 + 2 bytes
-// (the split-precision tower: a row is [hi: channels | lo: channels]).
+// (the split-precision tower: 128 bytes of a row are [hi of 32 channels | lo of the same 32]).
 enum class Act : int { F32 = 0, BF16 = 1, F16S = 2 };
 
 inline int act_bytes(Act a) { return a == Act::BF16 ? 2 : 4; }  // bytes of one activation in HBM
 // Input channels consumed per pipeline stage: one 128-byte LDS row.
-inline int act_kc(Act a) { return a == Act::F32 ? 32 : 64; }
+inline int act_kc(Act a) { return a == Act::BF16 ? 64 : 32; }
 // Element type of the head kernels (K3-K5) for a tower of type `a`: the split tower's heads run in exact f32.
 inline Act head_act(Act a) { return a == Act::BF16 ? Act::BF16 : Act::F32; }
 
@@ -42,8 +42,9 @@ struct StemInput {
     const uint64_t* planes;  // [n][C][w64]
     uint32_t n, C, w64;
 };
-// Act::F16S (split precision): in / res / out rows are [hi: c | lo: c] f16, w rows [hi: cin | lo: cin] f16 pre-scaled per
-// output channel by a power of two, bias is [cout bias | cout inverse scales]; cin counts the channels of one half.
+// Act::F16S (split precision): rows of in / res / out and of w are f16 pairs interleaved in groups of 32 channels,
+// [hi of channels 32g .. 32g+31 | lo of the same 32] per 128 bytes; w is pre-scaled per output channel by a power of
+// two, bias is [cout biases | cout inverse scales]; cin counts channels (pairs).
 // flags & 1 (F16S only): out is written as plain f32 [row][cout] (last tower layer, read by the f32 head kernels).
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,

@@ -275,14 +275,15 @@ struct StemPlanes<true> {
 //     k order per output element, so the result does not depend on which of the two ran.
 // SPLIT (T = _Float16; K1s, the split-precision tower): every activation and every weight is a PAIR of f16 values,
 //     x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 significant bits), and a product is three MFMA terms,
-//     a_hi w_hi + a_lo w_hi + a_hi w_lo, accumulated in f32 (a_lo w_lo, 2^-22 of the product, is dropped).  Rows of
-//     `in` / `res` / `out` are [hi: c channels | lo: c channels], rows of `w` [hi: cin | lo: cin]; the k walk goes over
-//     VIRTUAL chunks: real chunk c gives (a_hi, w_hi), (a_lo, w_hi), (a_hi, w_lo), so the loop below, the LDS map and
-//     the MFMA count per step are those of the bf16 kernel with three times the chunks (the stem's planes are 0/1, so
-//     its a_lo is zero: two virtual chunks on the one expanded activation chunk).  Weights are pre-scaled per output
-//     channel by a power of two (so that their lo halves are normal f16 numbers); `bias` is followed by the cout
-//     inverse scales, applied (exactly) in the epilogue.  flags & 1: the output is written as plain f32 [row][cout]
-//     instead of a pair (the last tower layer, for the f32 head kernels).
+//     a_hi w_hi + a_lo w_hi + a_hi w_lo, accumulated in f32 (a_lo w_lo, 2^-22 of the product, is dropped).  The pairs
+//     are interleaved in groups of 32 channels: a 128-byte row piece is [hi of 32 channels | lo of the same 32], in
+//     `in` / `res` / `out` rows and in `w` rows alike, so a chunk carries 32 channels (as in the f32 kernel), the
+//     loaders, the LDS map and the swizzle are those of the other types, and a consumer stage (tap, 16 channels) reads
+//     the hi and lo fragments of both operands once (8 ds_read_b128) for its 12 MFMAs.  The stem's planes are 0/1
+//     (their lo half is zero).  Weights are pre-scaled per output channel by a power of two (so that their lo halves
+//     are normal f16 numbers); `bias` is followed by the cout inverse scales, applied (exactly) in the epilogue.
+//     flags & 1: the output is written as plain f32 [row][cout] instead of pairs (the last tower layer, for the f32
+//     head kernels).
 constexpr int CONV_OUT_F32 = 1;
 
 template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2, bool SPLIT = false>
@@ -292,10 +293,10 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                            StemPlanes<STEM> sp) {
     static_assert(!SPLIT || sizeof(T) == 2, "split precision runs on 2-byte operands");
     static_assert(NLOAD == 4, "the stem expansion, the 32-cout tile and the piece counts below assume four loader waves");
-    constexpr int KC = 128 / (int)sizeof(T);
+    constexpr int ESZ = SPLIT ? 4 : (int)sizeof(T);  // bytes of one channel of a row (SPLIT: hi + lo)
+    constexpr int KC = 128 / ESZ;         // channels per 128-byte chunk
     constexpr int CPW = 32 * CB;          // output channels of this workgroup
     constexpr int WPLC = WPL * CB / 2;    // weight pieces per loader wave and step
-    constexpr int PARTS = SPLIT ? 2 : 1;  // hi | lo halves of a row
     typedef typename Mfma<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -316,10 +317,9 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
 
-    const int nch_real = cin / KC;                                       // 128-byte chunks of one half of a row
-    const int nch = SPLIT ? (STEM ? 2 : 3) * nch_real : nch_real;        // chunks the k walk visits (virtual ones with SPLIT)
+    const int nch = cin / KC;
     const int T_total = nch * 3;
-    const uint32_t row_bytes = (uint32_t)cin * sizeof(T) * PARTS;        // a row of `in` / `w`: [hi | lo] with SPLIT
+    const uint32_t row_bytes = (uint32_t)cin * ESZ;
 
     if (is_loader) {
         // ================================ loader waves ================================
@@ -349,23 +349,13 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
         auto issue_w = [&](int t) {  // weight slab of step t -> ring slot t % 3
             const int ch = t / 3, g = t - ch * 3;
-            int wch = ch;  // chunk of the weight rows: SPLIT walks (hi, hi, lo) per real chunk, the stem (hi, lo)
-            if constexpr (SPLIT && !STEM) {
-                const int c = ch / 3, j = ch - c * 3;
-                wch = c + (j == 2 ? nch_real : 0);
-            }
-            const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)wch * 128;
+            const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)ch * 128;
             char* dst = smem + V2_LDS_W + (t % 3) * V2_SLAB;
 #pragma unroll
             for (int i = 0; i < WPLC; i++) glds16(src + off_w[i], dst + dst_w[i]);
         };
         auto issue_a = [&](int ch, int g) {  // half g of activation chunk ch -> buffer ch & 1
-            int ach = ch;  // chunk of the activation rows: SPLIT walks (hi, lo, hi) per real chunk
-            if constexpr (SPLIT) {
-                const int c = ch / 3, j = ch - c * 3;
-                ach = c + (j == 1 ? nch_real : 0);
-            }
-            const char* src = abase0 + (size_t)ach * 128;
+            const char* src = abase0 + (size_t)ch * 128;
             char* dst = smem + V2_LDS_ACT + (ch & 1) * 32768;
 #pragma unroll
             for (int i = 0; i < APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
@@ -433,7 +423,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 issue_w(t + 2);
                 pending += WPLC;
             }
-            if (!STEM && g < 2 && ch + 1 < nch) {  // the stem has one activation chunk, expanded above
+            if (g < 2 && ch + 1 < nch) {
                 issue_a(ch + 1, g);
                 pending += APL;
             }
@@ -483,25 +473,36 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     // Epilogue operands that depend on nothing computed here are requested now, so their latency hides
     // under the main loop: the folded-BN bias of this lane's 8 cout quads, and (2-byte activations only,
     // for register budget) the skip-connection rows in the epilogue's (pixel row, 8 couts) layout.
-    f32x4 biasv[CB][4], dsv[SPLIT ? CB : 1][4];
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
-            if constexpr (SPLIT) dsv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cb * 32 + g * 8 + h * 4);
-        }
     // epilogue store layout: a pixel row of the tile is CPW couts = LPR lanes x 8 couts; 64 / LPR rows per trip
     constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = 64 / RPT;
     const int prow = lane / LPR, cg = lane % LPR;
-    constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2 && !SPLIT;
-    const size_t orow = (size_t)cout * PARTS;  // elements per row of `res` / `out`
-    T resv[EIT][8 * PARTS];
+    // bias: in the accumulator's layout (added before the transpose), 16 CB registers; SPLIT keeps the bias and the
+    // inverse weight scale of the 8 couts the lane owns AFTER the transpose instead (16 registers for both)
+    f32x4 biasv[SPLIT ? 1 : CB][4], bias8[2], ds8[2];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            bias8[q] = *reinterpret_cast<const f32x4*>(bias + cout0 + cg * 8 + q * 4);
+            ds8[q] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cg * 8 + q * 4);
+        }
+    } else {
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
+    }
+    constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2;
+    // a row of `res` / `out` in elements of T, and where this lane's 8 couts start in it (SPLIT: the hi values of the
+    // 32-channel group, the lo values 32 elements further)
+    const size_t orow = (size_t)cout * (SPLIT ? 2 : 1);
+    const int ocol = SPLIT ? ((cout0 + cg * 8) >> 5) * 64 + ((cout0 + cg * 8) & 31) : cout0 + cg * 8;
+    T resv[EIT][SPLIT ? 16 : 8];
     if (RES_EARLY) {
 #pragma unroll
         for (int i = 0; i < EIT; i++) {
-            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * orow + cout0 + cg * 8;
+            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * orow + ocol;
             *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
+            if constexpr (SPLIT) reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(res + off + 32);
         }
     }
 
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     constexpr int AHEAD = CB == 2 ? 2 : 3, RING = AHEAD + 1;
     int opaque = 0;
     for (int ch = 0; ch < nch; ch++) {
-        const int abase = V2_LDS_ACT + (STEM ? 0 : (ch & 1) * 32768) + board_lds;
+        const int abase = V2_LDS_ACT + (ch & 1) * 32768 + board_lds;
 #pragma unroll
         for (int g = 0; g < 3; g++) {
             // all fragment reads of the previous step have returned before the loaders may reuse its slab
@@ -539,6 +540,44 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
                 }
+            if constexpr (SPLIT) {
+                // A stage is (tap, 16 channels): the hi and lo fragments of CB weight blocks and of 2 pixel blocks
+                // (slots ks = k and ks = 2 + k of the 128-byte rows) feed 3 x 2 CB MFMAs: hi hi, hi lo, lo hi.
+                constexpr int SA = 1, SR = SA + 1;  // stages of look-ahead (a stage is 384 cycles of MFMA issue), register ring
+                frag sah[SR][CB], sal[SR][CB], sbh[SR][2], sbl[SR][2];
+                auto load_split = [&](int i, int s) {
+                    const int dxi = i >> 1, k = i & 1;
+#pragma unroll
+                    for (int cb = 0; cb < CB; cb++) {
+                        sah[s][cb] = *reinterpret_cast<const frag*>(smem + aaddr[k][cb] + (wslab + dxi * 8192));
+                        sal[s][cb] = *reinterpret_cast<const frag*>(smem + aaddr[2 + k][cb] + (wslab + dxi * 8192));
+                    }
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++) {
+                        sbh[s][pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][k]);
+                        sbl[s][pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][2 + k]);
+                    }
+                };
+#pragma unroll
+                for (int i = 0; i < SA; i++) load_split(i, i % SR);
+                __builtin_amdgcn_sched_group_barrier(0x100, (2 * CB + 4) * SA, 0);
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    if (i + SA < 6) load_split(i + SA, (i + SA) % SR);
+                    const int s = i % SR;
+#pragma unroll
+                    for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                        for (int pb = 0; pb < 2; pb++) {
+                            Mfma<T>::mac(sal[s][cb], sbh[s][pb], acc[cb][pb]);
+                            Mfma<T>::mac(sah[s][cb], sbl[s][pb], acc[cb][pb]);
+                            Mfma<T>::mac(sah[s][cb], sbh[s][pb], acc[cb][pb]);
+                        }
+                    if (i + SA < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2 * CB + 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, CB * 6, 0);
+                }
+                continue;
+            }
             frag fa[RING][CB], fb[RING][2];
             auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[2]) {
                 const int dxi = i >> 2, ks = i & 3;
@@ -584,10 +623,10 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         if (HAS_RES && !RES_EARLY) {
 #pragma unroll
             for (int i = 0; i < EIT; i++) {
-                const size_t off = (wrow0 + i * RPT + prow) * orow + cout0 + cg * 8;
-                if (SPLIT) {  // hi and lo halves of the row
+                const size_t off = (wrow0 + i * RPT + prow) * orow + ocol;
+                if (SPLIT) {  // hi and lo values of the 8 channels
                     reinterpret_cast<f32x4*>(resv[i])[0] = *reinterpret_cast<const f32x4*>(res + off);
-                    reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(res + off + cout);
+                    reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(res + off + 32);
                 } else if (sizeof(T) == 2) {
                     *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
                 } else {
@@ -605,13 +644,11 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             for (int pb = 0; pb < 2; pb++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const f32x4 bv = biasv[cb][g];
                     f32x4 v;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        // SPLIT: the accumulator carries the weights' power-of-two scale; times its inverse is exact
-                        if constexpr (SPLIT) v[i] = acc[cb][pb][g * 4 + i] * dsv[cb][g][i] + bv[i];
-                        else v[i] = acc[cb][pb][g * 4 + i] + bv[i];
+                        if constexpr (SPLIT) v[i] = acc[cb][pb][g * 4 + i];
+                        else v[i] = acc[cb][pb][g * 4 + i] + biasv[cb][g][i];
                     }
                     const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
                     *reinterpret_cast<f32x4*>(smem + stage_row(pb * 32 + r) + slot * 16) = v;
@@ -623,7 +660,12 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (px & 7)) << 4));
             const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (px & 7)) << 4));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const size_t off = (wrow0 + px) * orow + cout0 + cg * 8;
+            if constexpr (SPLIT) {
+                // the accumulator carries the weights' power-of-two scale: times its inverse is exact
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = v[j] * ds8[j >> 2][j & 3] + bias8[j >> 2][j & 3];
+            }
+            const size_t off = (wrow0 + px) * orow + ocol;
             if (HAS_RES) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -653,7 +695,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                         lo[j] = (T)(yc - (float)hi[j]);
                     }
                     __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(hi), reinterpret_cast<f32x4*>(out + off));
-                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(lo), reinterpret_cast<f32x4*>(out + off + cout));
+                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(lo), reinterpret_cast<f32x4*>(out + off + 32));
                 }
                 continue;
             }

@@ -42,6 +42,8 @@ ABI_SYMBOLS = [
     "cattus_sp_trace_game",
     "cattus_sp_trace_game_ex",
     "cattus_sp_play_moves",
+    "cattus_sp_test_dirichlet",
+    "cattus_sp_test_temperature_choice",
     "cattus_sp_pos_new",
     "cattus_sp_pos_free",
     "cattus_sp_pos_status",
@@ -145,6 +147,8 @@ def load_library():
     L.cattus_sp_trace_game_ex.argtypes = [C.c_int, C.POINTER(SpConfig), vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_size_t]
     L.cattus_sp_trace_game_ex.restype = C.c_int64
     L.cattus_sp_play_moves.argtypes = [C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.cattus_sp_test_dirichlet.argtypes = [C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, vp]
+    L.cattus_sp_test_temperature_choice.argtypes = [C.c_uint64, vp, C.c_uint32, C.c_float, C.c_uint32, vp]
     L.cattus_sp_pos_new.argtypes = [C.c_int, C.c_char_p]
     L.cattus_sp_pos_new.restype = vp
     L.cattus_sp_pos_free.argtypes = [vp]
@@ -478,6 +482,23 @@ class Position:
         return bytes(buf)
 
 
+def dirichlet_draws(seed: int, alpha: float, k: int, draws: int) -> np.ndarray:
+    """`draws` samples [draws, k] of the search's root-noise distribution Dir(alpha, ..., alpha) (mcts/mod.rs:419-446)."""
+    out = np.zeros((draws, k), dtype=np.float64)
+    if load_library().cattus_sp_test_dirichlet(seed, alpha, k, draws, out.ctypes.data) != 0:
+        raise ValueError("bad arguments")
+    return out
+
+
+def temperature_choice_counts(seed: int, probs, temperature: float, draws: int) -> np.ndarray:
+    """How often each of the moves with visit probabilities `probs` is chosen at `temperature` > 0 (mcts/mod.rs:403-415)."""
+    p = np.ascontiguousarray(probs, dtype=np.float32)
+    counts = np.zeros(len(p), dtype=np.uint32)
+    if load_library().cattus_sp_test_temperature_choice(seed, p.ctypes.data, len(p), temperature, draws, counts.ctypes.data) != 0:
+        raise ValueError("bad arguments")
+    return counts
+
+
 def chess_perft(fen: str, depth: int) -> int:
     return int(load_library().cattus_sp_chess_perft(fen.encode(), depth))
 
@@ -536,7 +557,7 @@ def main(argv=None):
     def load(path):
         blob = Path(path).read_bytes()
         return HipEvaluator(blob, batch_size=engine["model"]["batch_size"], plane_words=info["plane_words"],
-                            dtype=inf.get("dtype", "bf16"), device=inf.get("device", 0))
+                            dtype=inf.get("dtype", "f16x2"), device=inf.get("device", 0))
 
     ev1 = load(args.model1_path)
     same = os.path.abspath(args.model1_path) == os.path.abspath(args.model2_path)

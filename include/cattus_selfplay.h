@@ -128,6 +128,14 @@ int64_t cattus_sp_trace_game_ex(int game, const cattus_sp_config* cfg, cattus_ne
  * applied. */
 int cattus_sp_play_moves(int game, const uint16_t* moves, uint32_t n, uint32_t* plies_played);
 
+/* Known-answer hooks for the stochastic paths, running the very functions the search calls:
+ * `draws` samples of the root-noise distribution Dir(alpha, ..., alpha) over k moves (mcts/mod.rs:419-446,
+ * util/dirichlet.rs:226-352) into out[draws][k], and `draws` move choices at a temperature > 0 among k moves with
+ * visit probabilities probs[k] (mcts/mod.rs:403-415: chosen with probability ~ p^(1/T)) tallied into counts[k]. */
+int cattus_sp_test_dirichlet(uint64_t seed, float alpha, uint32_t k, uint32_t draws, double* out);
+int cattus_sp_test_temperature_choice(uint64_t seed, const float* probs, uint32_t k, float temperature, uint32_t draws,
+                                      uint32_t* counts);
+
 /* ---- position handles (rule tests) ---------------------------------------------------------- */
 typedef struct cattus_pos cattus_pos;
 /* str: NULL = initial position; ttt "xo_..."+turn, hex "reb..."+turn (test_util.rs:7-66), chess FEN */

@@ -37,7 +37,7 @@ print(f"  consumers: prologue (start->first barrier passed) {np.median(cons[...,
       f"epilogue {np.median(cons[...,3]-cons[...,2]):.0f}; of the loop, blocked at barriers {np.median(cons[...,4]):.0f}")
 print(f"  loaders  : lifetime {np.median(load[...,3]-load[...,0]):.0f}, waiting for data (vmcnt) {np.median(load[...,4]):.0f}, "
       f"waiting at barriers {np.median(load[...,7]):.0f}; prologue {np.median(load[...,1]-load[...,0]):.0f}")
-mfma = {"bf16": 12 * 48 * 32, "f32": 24 * 192 * 64}[dtype]
+mfma = {"bf16": 12 * 48 * 32, "f32": 24 * 192 * 64, "f16x2": 24 * 72 * 32}[dtype]
 print(f"  MFMA-bound loop time {mfma} cycles -> loop efficiency {mfma/np.median(cons[...,2]-cons[...,1]):.2f}, kernel efficiency {mfma/np.median(tot):.2f}")
 span = (cons[..., 6].max() - cons[..., 5].min()) / 100.0  # us on the 100 MHz real-time counter, one time base for all XCDs
 starts = (cons[..., 5] - cons[..., 5].min()) / 100.0
@@ -47,3 +47,10 @@ print(f"  first wave start -> last wave end over all workgroups: {span:.2f} us; 
       f"(the difference is dispatch before the first wave and completion after the last)")
 print(f"  wave start after the first one: median {np.median(starts):.2f} us, max {starts.max():.2f} us; "
       f"wave end before the last one: median {np.median(ends):.2f} us, max {ends.max():.2f} us")
+# who ends late: by XCD (blockIdx % 8 share one), and the spread of the consumer phases over workgroups
+endt = (cons[..., 6].max(axis=1) - cons[..., 5].min()) / 100.0
+print("  workgroup end (us after the first wave start) by blockIdx % 8:", " ".join(f"{endt[x::8].mean():.2f}" for x in range(8)),
+      f"| min {endt.min():.2f} median {np.median(endt):.2f} max {endt.max():.2f}")
+for name, a, b in (("prologue", 0, 1), ("loop", 1, 2), ("epilogue", 2, 3)):
+    ph = (cons[..., b] - cons[..., a]).max(axis=1)
+    print(f"  {name}: per-workgroup cycles min {ph.min():.0f} median {np.median(ph):.0f} p90 {np.percentile(ph, 90):.0f} max {ph.max():.0f}")

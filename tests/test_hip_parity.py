@@ -4,8 +4,11 @@ Bars (DESIGN.md "Parity"):
   * planes_to_tensor: bit-exact (values are 0.0 / 1.0).
   * dtype f32: bit-exact against the oracle (same fmaf-chain order on both sides) and within the
     reference's cross-runtime tolerance of the reference network's own outputs (tests/golden).
-  * dtype bf16: bf16 operands / f32 accumulation; tolerance stated in BF16_* below.
-  * per-leaf results never depend on batch size, slot or neighbours (both dtypes, bit-exact).
+  * dtype f16x2 (split precision, the product default): within the reference's cross-runtime tolerance of the
+    reference network's outputs on every fixture, and as close to the float64 run of the reference network as an
+    f32 runtime is (bounds F16X2_* below).
+  * dtype bf16: bf16 operands / f32 accumulation; per-fixture bounds in BF16_MEASURED below (2x the measured error).
+  * per-leaf results never depend on batch size, slot or neighbours (all dtypes, bit-exact).
 """
 
 import threading
@@ -22,8 +25,20 @@ from helpers import blob_for, golden_names, outputs_equal_ref_tol
 
 pytestmark = pytest.mark.gpu
 
-# bf16 tower vs f32 oracle: |dlogit| <= BF16_POLICY_ATOL + BF16_POLICY_RTOL*|logit|, |dvalue| <= BF16_VALUE_ATOL
-BF16_POLICY_RTOL, BF16_POLICY_ATOL, BF16_VALUE_ATOL = 5e-2, 5e-2, 3e-2
+# bf16 tower against the reference network's outputs: measured max |dlogit|, max |dvalue| per fixture (round 3,
+# scripts/split_check.py -> profiles/r03_split_check.json); the tests allow twice that, so a precision regression
+# goes red.  On the 256- / 512-leaf synthetic batches of the full-size tests the maxima over that many leaves are
+# larger than over a fixture's few: BF16_FULL[net] = 2x the measured 0.00842 / 0.00214 (chess 20x256, 256 leaves) and
+# 0.0260 / 0.00582 (chess 40x384, 512 leaves).
+BF16_MEASURED = {
+    "chess_1x1": (4.6e-4, 1e-6), "chess_20x256": (7.5e-3, 1.15e-3), "chess_2x64": (2.2e-3, 3.5e-4), "chess_7x16": (3.9e-3, 2.0e-4),
+    "hex11_1x1": (4.0e-4, 5.7e-5), "hex11_2x8": (1.1e-3, 3.5e-4), "hex4_7x16": (2.5e-3, 2.6e-4), "hex7_6x64": (3.2e-3, 5.8e-4),
+    "ttt_1x1": (2.3e-4, 1e-6), "ttt_2x64": (1.9e-3, 7.6e-4), "ttt_5x8": (2.7e-3, 7.4e-4),
+}
+BF16_FULL = {"20x256": (1.7e-2, 4.3e-3), "40x384": (5.2e-2, 1.2e-2)}
+# split precision against the float64 run of the reference network: measured max |dlogit| 7.4e-7, |dvalue| 2.1e-7 (chess
+# 20x256; the bit-exact f32 tower: 7.7e-7 / 1.9e-7, the reference's own f32 run: 3.3e-7 / 4.9e-8)
+F16X2_POLICY_ATOL_VS_F64, F16X2_VALUE_ATOL_VS_F64 = 1.5e-6, 5e-7
 
 # every fixture runs on the MFMA tower: filters are padded to 64 channels, boards above 8x8 take 128 pixel slots
 MFMA_SHAPES = golden_names()
@@ -64,11 +79,7 @@ def test_f32_bit_exact_vs_oracle_and_reference_tolerance(name):
         got_p, got_v = ev.eval(planes)
     assert (got_p == want_p).all(), f"max |dp| = {np.abs(got_p - want_p).max()}"
     assert (got_v == want_v).all(), f"max |dv| = {np.abs(got_v - want_v).max()}"
-    if name != "chess_20x256":
-        assert outputs_equal_ref_tol(got_p, got_v, z["policy"], z["value"])
-    else:
-        np.testing.assert_allclose(got_p, z["policy"], rtol=2e-3, atol=2e-5)
-        np.testing.assert_allclose(got_v, z["value"], rtol=1e-4, atol=1e-5)
+    assert outputs_equal_ref_tol(got_p, got_v, z["policy"], z["value"])  # the 20-block net too
 
 
 @pytest.mark.parametrize("name", MFMA_SHAPES)
@@ -79,8 +90,48 @@ def test_bf16_within_stated_tolerance(name):
         got_p, got_v = ev.eval(planes)
     ref_p, ref_v = z["policy"], z["value"]
     assert np.isfinite(got_p).all() and np.isfinite(got_v).all()
-    assert (np.abs(got_p - ref_p) <= BF16_POLICY_ATOL + BF16_POLICY_RTOL * np.abs(ref_p)).all(), np.abs(got_p - ref_p).max()
-    assert (np.abs(got_v - ref_v) <= BF16_VALUE_ATOL).all(), np.abs(got_v - ref_v).max()
+    dp, dv = BF16_MEASURED[name]
+    assert np.abs(got_p - ref_p).max() <= 2 * dp, np.abs(got_p - ref_p).max()
+    assert np.abs(got_v - ref_v).max() <= 2 * dv, np.abs(got_v - ref_v).max()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_f16x2_within_the_reference_tolerance(name):
+    """The split-precision tower (pairs of f16 values, three MFMA terms per product, f32 heads) against the outputs of
+    the reference's own network (tests/golden, made with training/cattus_train/net_utils.py): inside the reference's
+    cross-runtime bar (training/tests/test_net_output.py:28-33: policy rtol 1e-3 / atol 1e-6, value rel 1e-5 / abs
+    1e-6) on EVERY fixture, the 20-block one included, and as close to the reference's float64 run as f32 arithmetic gets."""
+    d, blob, z = blob_for(name)
+    planes = z["planes"]
+    with HipEvaluator(blob, batch_size=len(planes) + 2, plane_words=_plane_words(planes), dtype="f16x2") as ev:
+        got_p, got_v = ev.eval(planes)
+    assert outputs_equal_ref_tol(got_p, got_v, z["policy"], z["value"])
+    assert np.abs(got_p - z["policy_f64"]).max() <= F16X2_POLICY_ATOL_VS_F64, np.abs(got_p - z["policy_f64"]).max()
+    assert np.abs(got_v - z["value_f64"]).max() <= F16X2_VALUE_ATOL_VS_F64, np.abs(got_v - z["value_f64"]).max()
+
+
+def test_f16x2_range_large_batchnorm_scales():
+    """f16 holds 65504 at most.  Weights are safe whatever their size (each output channel is pre-scaled by a power of two
+    and un-scaled exactly in the epilogue); activations are stored as they are.  A stem BatchNorm weight of 200 puts
+    the residual stream in the hundreds -- the split tower still tracks the f32 oracle to 22 bits --; one of 1e5 sends
+    it beyond the f16 range, where the epilogue saturates at 65504 instead of producing infinities."""
+    from cattus_amd.weights import pack_tensors, seeded_tensors
+
+    d = NetDesc(**CHESS, blocks=2, filters=64, vhc=8, phc=8)
+    planes = synth.random_chess_planes(9, 4)
+    for scale, finite_only in ((200.0, False), (1e5, True)):
+        t = seeded_tensors(d, 6)
+        t["_conv1._bn.weight"] = t["_conv1._bn.weight"] * np.float32(scale)
+        t["_residual_blocks.0._conv1.weight"] = t["_residual_blocks.0._conv1.weight"] * np.float32(1e-3)  # tiny weights too
+        blob = pack_tensors(d, t)
+        want_p, want_v = oracle.OracleNet(blob).forward(planes)
+        with HipEvaluator(blob, batch_size=16, plane_words=1, dtype="f16x2") as ev:
+            p, v = ev.eval(planes)
+        assert np.isfinite(p).all() and np.isfinite(v).all()
+        if not finite_only:
+            assert np.abs(want_p).max() > 20  # the scale did reach the logits
+            np.testing.assert_allclose(p, want_p, rtol=2e-5, atol=2e-5 * np.abs(want_p).max())
+            np.testing.assert_allclose(v, want_v, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["chess_7x16", "hex11_2x8", "ttt_5x8", "hex4_7x16", "hex11_1x1"])
@@ -142,7 +193,7 @@ def test_resident_tower_row_splits_agree(monkeypatch):
     """The resident tower picks 128- or 64-row workgroups (CH = 2, 4) by batch size, and with 64 rows and a
     board of <= 63 pixels walks a layer as one step; the split changes which wave holds which tile and when the
     waves meet, not the arithmetic of an output element: forced one after the other on the same batch
-    (CATTUS_T64_CH / CATTUS_T64_LS, read per forward pass) they give the bits of the per-layer launches."""
+    (CATTUS_T64_CH / CATTUS_T64_LS, read when an evaluator is created) they give the bits of the per-layer launches."""
     d = NetDesc(**hex_game(7), blocks=4, filters=64, vhc=16, phc=16)
     blob = seeded_blob(d, 23)
     rng = np.random.default_rng(9)
@@ -155,10 +206,10 @@ def test_resident_tower_row_splits_agree(monkeypatch):
     with HipEvaluator(blob, batch_size=n, plane_words=2, dtype="bf16") as ev:
         want_p, want_v = ev.eval(planes)
     monkeypatch.delenv("CATTUS_TOWER64")
-    with HipEvaluator(blob, batch_size=n, plane_words=2, dtype="bf16") as ev:
-        for ch, ls in (("4", "1"), ("2", "1"), ("4", "0"), ("4", "1")):
-            monkeypatch.setenv("CATTUS_T64_CH", ch)
-            monkeypatch.setenv("CATTUS_T64_LS", ls)  # 64-row workgroups: one barrier per layer (default) or three
+    for ch, ls in (("4", "1"), ("2", "1"), ("4", "0")):
+        monkeypatch.setenv("CATTUS_T64_CH", ch)
+        monkeypatch.setenv("CATTUS_T64_LS", ls)  # 64-row workgroups: one barrier per layer (default) or three
+        with HipEvaluator(blob, batch_size=n, plane_words=2, dtype="bf16") as ev:
             got_p, got_v = ev.eval(planes)
             assert (got_p == want_p).all() and (got_v == want_v).all(), (ch, ls)
             one_p, one_v = ev.eval(planes[77:78])
@@ -183,7 +234,7 @@ def test_fused_stem_equals_separate_plane_pack(name, dtype, monkeypatch):
     assert (got_p == want_p).all() and (got_v == want_v).all()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16x2"])
 @pytest.mark.parametrize("game,desc,words,n", [
     ("chess", dict(**CHESS, blocks=3, filters=256, vhc=8, phc=8), 1, 70),
     ("hex11", dict(**hex_game(11), blocks=2, filters=128, vhc=16, phc=16), 2, 21),
@@ -224,7 +275,7 @@ def test_wide_heads_take_the_generic_path_and_refuse_bf16():
     assert ei.value.status == -2
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16x2"])
 def test_rows_independent_of_batch_composition(dtype):
     d = NetDesc(**CHESS, blocks=3, filters=64, vhc=8, phc=8)
     blob = seeded_blob(d, 77)
@@ -265,7 +316,7 @@ def test_non_finite_logits_are_scrubbed():
     blob = pack_tensors(d, t)
     planes = synth.random_hex_planes(3, 4, 9)
     want_p, want_v = oracle.OracleNet(blob).forward(planes)
-    for dtype in ("f32", "bf16"):
+    for dtype in ("f32", "bf16", "f16x2"):
         with HipEvaluator(blob, batch_size=4, plane_words=2, dtype=dtype) as ev:
             p, v = ev.eval(planes)
         fmin = np.finfo(np.float32).min
@@ -274,7 +325,7 @@ def test_non_finite_logits_are_scrubbed():
     assert (want_p[:, 3] == fmin).all() and (want_p[:, 7] == fmin).all()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16x2"])
 def test_leaf_server_matches_blocking_eval(dtype):
     d = NetDesc(**hex_game(7), blocks=2, filters=64, vhc=16, phc=16)
     blob = seeded_blob(d, 3)
@@ -327,18 +378,31 @@ def test_full_size_chess_20x256_batch_256():
     rows = np.arange(0, 256, 16)
     want_p, want_v = oracle.OracleNet(blob).forward(planes[rows])
     assert (p32[rows] == want_p).all() and (v32[rows] == want_v).all()
+    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
+        ps, vs = ev.eval(planes)
+        pp, vp = ev.eval(planes[perm])
+        assert (pp == ps[perm]).all() and (vp == vs[perm]).all()
+        pr, vr = ev.eval(planes[:255])
+        assert (pr == ps[:255]).all() and (vr == vs[:255]).all()
+    # the split tower against the bit-exact f32 tower, all 256 rows: inside the reference's cross-runtime bar, and two
+    # f32-grade roundings apart at most (each is <= 1e-6 / 3e-7 from the float64 truth)
+    assert outputs_equal_ref_tol(ps, vs, p32, v32)
+    assert np.abs(ps - p32).max() <= 3e-6 and np.abs(vs - v32).max() <= 1e-6, (np.abs(ps - p32).max(), np.abs(vs - v32).max())
+    assert (ps.argmax(1) == p32.argmax(1)).all()
     with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="bf16") as ev:
         p16, v16 = ev.eval(planes)
         pp, vp = ev.eval(planes[perm])
         assert (pp == p16[perm]).all() and (vp == v16[perm]).all()
-    assert (np.abs(p16 - p32) <= BF16_POLICY_ATOL + BF16_POLICY_RTOL * np.abs(p32)).all(), np.abs(p16 - p32).max()
-    assert (np.abs(v16 - v32) <= BF16_VALUE_ATOL).all(), np.abs(v16 - v32).max()
+    print("chess 20x256, 256 leaves: bf16 vs f32 max |dlogit| %.4g |dvalue| %.4g; f16x2 vs f32 %.3g %.3g" % (
+        np.abs(p16 - p32).max(), np.abs(v16 - v32).max(), np.abs(ps - p32).max(), np.abs(vs - v32).max()))
+    assert np.abs(p16 - p32).max() <= BF16_FULL["20x256"][0], np.abs(p16 - p32).max()
+    assert np.abs(v16 - v32).max() <= BF16_FULL["20x256"][1], np.abs(v16 - v32).max()
     # greedy move agreement between the two dtypes (reported, loosely bounded)
     agree = (p16.argmax(1) == p32.argmax(1)).mean()
     assert agree >= 0.9, agree
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16x2"])
 def test_eval_legal_softmax_bit_exact_vs_restatement(dtype):
     """cattus_hip_eval_legal = cattus_hip_eval + calc_moves_probs (net/mod.rs:100-119) on the device:
     bit-exact against the oracle's restatement applied to the same evaluator's logits, within 1e-6 of
@@ -412,8 +476,15 @@ def test_full_size_chess_40x384_batch_512():
         pp, vp = ev.eval(planes[perm])
         assert (pp == p16[perm]).all() and (vp == v16[perm]).all()
     assert np.isfinite(p16).all() and np.isfinite(v16).all()
-    assert (np.abs(p16 - p32) <= BF16_POLICY_ATOL + BF16_POLICY_RTOL * np.abs(p32)).all(), np.abs(p16 - p32).max()
-    assert (np.abs(v16 - v32) <= BF16_VALUE_ATOL).all(), np.abs(v16 - v32).max()
+    print("chess 40x384, 512 leaves: bf16 vs f32 max |dlogit| %.4g |dvalue| %.4g" % (np.abs(p16 - p32).max(), np.abs(v16 - v32).max()))
+    assert np.abs(p16 - p32).max() <= BF16_FULL["40x384"][0], np.abs(p16 - p32).max()
+    assert np.abs(v16 - v32).max() <= BF16_FULL["40x384"][1], np.abs(v16 - v32).max()
+    with HipEvaluator(blob, batch_size=512, plane_words=1, dtype="f16x2") as ev:
+        ps, vs = ev.eval(planes)
+        pr, vr = ev.eval(planes[100:357])
+        assert (pr == ps[100:357]).all() and (vr == vs[100:357]).all()
+    print("chess 40x384, 512 leaves: f16x2 vs f32 max |dlogit| %.3g |dvalue| %.3g" % (np.abs(ps - p32).max(), np.abs(vs - v32).max()))
+    assert outputs_equal_ref_tol(ps, vs, p32, v32)
 
 
 def test_device_pointer_entry_points_and_lanes_agree_with_host_entry_point():

@@ -8,9 +8,9 @@ times (BASELINE config 3: 800 simulations per move):
     count) -- at a size the oracle finishes in seconds -- and, for the full-size run below, leaf for leaf
     on a sample of the positions the games went through.
  2. f32 evaluator, 800 sims/move, 16 games x 16 searched plies: the reference-precision search.
- 3. bf16 evaluator searching the SAME positions (teacher-forced, cattus_amd/agreement.py): chosen-move
-    agreement and L1 distance of the root visit distributions are reported and bounded (floors stated in
-    DESIGN.md section 4).
+ 3. the split-precision evaluator (f16x2, the product default) and the bf16 evaluator searching the SAME positions
+    (teacher-forced, cattus_amd/agreement.py): chosen-move agreement and L1 distance of the root visit distributions
+    are reported and bounded (floors stated below and in DESIGN.md section 4).
 
 Reference: engine/src/mcts/mod.rs:156-196 (search), :387-417 (greedy choice), training/tests/test_net_output.py:28-33
 (the reference's own bar is per-leaf; there is none at search level)."""
@@ -31,10 +31,14 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 # floors for statement 3; measured values go to gpurun_out/search_agreement.json
-# measured (round 2, 256 searched plies): agreement 0.941, L1 mean 0.0037, p95 0.015, max 0.045
-BF16_MOVE_AGREEMENT_MIN = 0.88
-BF16_VISIT_L1_MEAN_MAX = 0.015
-BF16_VISIT_L1_MAX = 0.12
+# bf16, measured (256 searched plies): agreement 0.941, L1 mean 0.0037, p95 0.015, max 0.045 -> about twice that
+BF16_MOVE_AGREEMENT_MIN = 0.90
+BF16_VISIT_L1_MEAN_MAX = 0.0075
+BF16_VISIT_L1_MAX = 0.09
+# f16x2 (per-leaf error ~1e-6): a near-tie in a PUCT comparison can still fall the other way; over these 256 searches
+# at most 2 chosen moves may differ (>= 99.2 %), see profiles/r03_search_agreement_f16x2.json for 2,048 and 3,888 searches
+F16X2_MOVE_AGREEMENT_MIN = 0.992
+F16X2_VISIT_L1_MEAN_MAX = 4e-4
 
 
 def _positions_of(lines, upto):
@@ -79,7 +83,18 @@ def test_chess_20x256_search_f32_equals_oracle_and_bf16_agreement_is_bounded():
         p_or, v_or = onet.forward(sample[:games])
         assert (p_hip == p_or).all() and (v_hip == v_or).all()
 
-    # ---- 3. bf16 on the same positions
+    # ---- 3a. the split-precision tower on the same positions
+    with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="f16x2", flush_us=100) as evs:
+        ts = ag.run_traces("chess", cfg, sp.Net.hip_batched(evs), lines, 2, plies)
+        assert ts == ag.run_traces("chess", cfg, sp.Net.hip_batched(evs), lines, 2, plies)  # reproducible
+        ps, vs = evs.eval(sample[:games])
+    res_s = ag.compare_traces(ta, ts)
+    res_s.update(dtype="f16x2", leaf_max_abs_dlogit=float(np.abs(ps - p_or).max()), leaf_max_abs_dvalue=float(np.abs(vs - v_or).max()))
+    print("f16x2 vs f32 search agreement:", json.dumps(res_s))
+    assert res_s["move_agreement"] >= F16X2_MOVE_AGREEMENT_MIN, res_s
+    assert res_s["visit_l1_mean"] <= F16X2_VISIT_L1_MEAN_MAX, res_s
+
+    # ---- 3b. bf16 on the same positions
     with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="bf16", flush_us=100) as ev16:
         t16 = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev16), lines, 2, plies)
         again = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev16), lines, 2, plies)
@@ -91,7 +106,7 @@ def test_chess_20x256_search_f32_equals_oracle_and_bf16_agreement_is_bounded():
                leaf_argmax_agreement=float((p16.argmax(1) == p_or.argmax(1)).mean()))
     out = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent)) / "gpurun_out"
     out.mkdir(exist_ok=True)
-    (out / "search_agreement.json").write_text(json.dumps(res, indent=1))
+    (out / "search_agreement.json").write_text(json.dumps({"bf16": res, "f16x2": res_s}, indent=1))
     print("bf16 vs f32 search agreement:", json.dumps(res))
     assert res["plies"] >= games * plies - 8
     assert res["move_agreement"] >= BF16_MOVE_AGREEMENT_MIN, res

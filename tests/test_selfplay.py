@@ -301,3 +301,20 @@ def test_cache_is_one_fifo_of_max_size():
         big = sp.run_self_play("hex5", _cfg(sim_num=30, cache_size=100000), sp.Net.python(net), None, 2)
         assert (big["record_bytes"] == res["record_bytes"]).all()  # results never depend on the cache
         assert big["cache_misses"] <= res["cache_misses"]
+
+
+def test_self_player_executables_exist_for_every_game_and_start_from_any_directory(tmp_path):
+    """bin/<game>_self_player (the names training/cattus_train/self_play.py:44 builds): present for every game the
+    reference has a binary for, executable, and importable from a foreign working directory (`--help` needs no GPU)."""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(sp.__file__).resolve().parent.parent
+    for game in ("tictactoe", "hex4", "hex5", "hex7", "hex9", "hex11", "hex", "chess"):
+        exe = root / "bin" / f"{game}_self_player"
+        assert exe.exists() and exe.stat().st_mode & 0o111, exe
+    out = subprocess.run([str(root / "bin" / "chess_self_player"), "--help"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert out.returncode == 0 and "--model1-path" in out.stdout and "--summary-file" in out.stdout
+    # a missing required flag is an argument error (clap exits non-zero as well)
+    bad = subprocess.run([str(root / "bin" / "hex4_self_player"), "--games-num=2"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert bad.returncode != 0

@@ -75,6 +75,58 @@ def test_self_player_cli_contract(tmp_path):
         assert f.stat().st_size == records.record_nbytes("hex5")
 
 
+def test_self_player_executable_as_the_trainer_launches_it(tmp_path):
+    """bin/<game>_self_player exactly as training/cattus_train/train_process.py:159-186 runs the reference's binary:
+    `--flag=value` arguments, no --game, a foreign working directory, the engine JSON written with json.dump, and the
+    summary read back through the same keys the trainer reads (default dtype: the split-precision tower)."""
+    d = NetDesc(**hex_game(5), blocks=1, filters=64, vhc=4, phc=4)
+    model_dir = tmp_path / "models" / "model_x" / "self_play"
+    model_dir.mkdir(parents=True)
+    model_path = model_dir / "model.cattus"
+    model_path.write_bytes(seeded_blob(d, 9))
+    engine_cfg = {
+        "model": {"inference": {"engine": "hip"}, "batch_size": 8},
+        "mcts": {"sim_num": 12, "explore_factor": 1.41421, "temperature_policy": [[2, 1.0], [9999, 0.0]], "prior_noise_alpha": 0.3,
+                 "prior_noise_epsilon": 0.25, "cache_size": 1000},
+        "threads": 2,
+    }
+    cfg_file = tmp_path / "config.json"
+    cfg_file.write_text(json.dumps(engine_cfg, indent=2))
+    summary_file = tmp_path / "selfplay_summary.json"
+    data_entries_dir = tmp_path / "games" / "run" / "250101_000000_000000"
+    foreign_cwd = tmp_path / "self-play-crate"
+    foreign_cwd.mkdir()
+    exe = sp._PKG.parent / "bin" / "hex5_self_player"
+    subprocess.check_call(
+        [
+            str(exe),
+            f"--model1-path={model_path}",
+            f"--model2-path={model_path}",
+            "--games-num=4",
+            f"--out-dir1={data_entries_dir}",
+            f"--out-dir2={data_entries_dir}",
+            f"--summary-file={summary_file}",
+            f"--config-file={cfg_file}",
+        ],
+        cwd=str(foreign_cwd),
+    )
+    summary = json.loads(summary_file.read_text())
+    metrics = {  # train_process.py:176-186
+        "net_activations_count": summary["metrics"]["model.activation_count"],
+        "net_run_duration_average_us": summary["metrics"]["model.run_duration"],
+        "search_duration": summary["metrics"]["mcts.search_duration"],
+        "cache_hit_ratio": summary["metrics"]["cache.hits"] / (summary["metrics"]["cache.hits"] + summary["metrics"]["cache.misses"]),
+    }
+    assert metrics["net_activations_count"] > 0 and metrics["net_run_duration_average_us"] > 0 and metrics["search_duration"] > 0
+    assert summary["player1_wins"] + summary["player2_wins"] + summary["draws"] == 4
+    files = sorted(data_entries_dir.iterdir())
+    assert files and all(f.name.endswith(".traindata") and f.stat().st_size == records.record_nbytes("hex5") for f in files)
+    # the summary file is created with create_new (self_play_cmd.rs:139-143): a second run on the same path fails
+    assert subprocess.call([str(exe), f"--model1-path={model_path}", f"--model2-path={model_path}", "--games-num=2",
+                            f"--out-dir1={data_entries_dir}", f"--out-dir2={data_entries_dir}", f"--summary-file={summary_file}",
+                            f"--config-file={cfg_file}"], cwd=str(foreign_cwd), stderr=subprocess.DEVNULL) != 0
+
+
 @pytest.mark.parametrize("game,desc,words", [("hex7", dict(**hex_game(7), blocks=2, filters=64, vhc=16, phc=16), 2), ("chess", dict(**CHESS, blocks=2, filters=64, vhc=8, phc=8), 1)])
 def test_device_softmax_games_equal_host_restatement(game, desc, words):
     """cattus_hip_eval_legal inside the driver: the records equal those of a driver whose network is
