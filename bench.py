@@ -2,19 +2,22 @@
 """Headline benchmark: MCTS node-evaluations per second on the chess 20x256 network, batch 256.
 
 One "step" = one pass of the leaf-evaluation hot path over one batch of 256 synthetic leaf
-positions: bitboard planes (already resident in HBM) -> plane-pack -> 41 fused 3x3 conv+BN+ReLU
-launches -> policy/value heads -> logits + values in HBM.  ``value`` is leaves evaluated per
+positions: bitboard planes (already resident in HBM) -> 41 fused 3x3 conv+BN+ReLU launches (the stem
+expands the planes itself) -> policy/value heads -> logits + values in HBM.  ``value`` is leaves evaluated per
 second summed over all ranks (weak scaling: every GPU runs its own batch stream, as self-play
 games shard across GPUs with no collective on the evaluation path).
 
-Beside the headline (bf16 tower) the same JSON line carries
-  f32                     the same steps on the exact-f32 tower (the reference's precision), with its own roofline
-  bf16_search_agreement   what the bf16 tower does to the SEARCH: 800-sim searches of the same positions with
-                          both towers (cattus_amd/agreement.py)
+The headline dtype is ``f16x2``, the split-precision tower: inside the reference's own cross-runtime tolerance per leaf
+and, at search level, the visit distributions of the exact-f32 search.  Beside it the same JSON
+line carries
+  bf16                    the same steps on the bf16 tower (throughput mode, 8 significant bits), with its own roofline
+  f32                     the same steps on the exact-f32 tower (bit-identical to the CPU oracle), with its own roofline
+  search_agreement        what each reduced-cost tower does to the SEARCH: 800-sim searches of the same positions with
+                          the f32 tower and with it (cattus_amd/agreement.py)
   selfplay                BASELINE config 3 end to end: C++ search at 800 sims/move feeding this GPU (bounded sample)
   selfplay_full_games     whole games at a reduced simulation count (a measured games/hour)
   selfplay_config4        BASELINE config 4's shape: 64 concurrent games per GPU, records pooled over RCCL in the timed path
-  cpu_baseline            the CPU path on this host's cores: evaluator (oracle network) and search + oracle network
+  cpu_baseline            the CPU path on this host's cores: evaluator (oracle C port and torch CPU) and search + oracle network
 
     python bench.py                       # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -24,6 +27,7 @@ Beside the headline (bf16 tower) the same JSON line carries
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,13 +36,24 @@ from pathlib import Path
 
 import numpy as np
 
-# kernel arguments in device memory (read by the HIP runtime when it initialises; cattus_amd/csrc/evaluator.hip)
+# kernel arguments in device memory (read by the HIP runtime when it initialises)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md: the f16 and bf16 forms issue at the same rate
+MFMA_PEAK_TFLOPS = {"f16x2": 2500.0, "bf16": 2500.0, "f32": 157.3}
+# MFMA instructions executed per algorithmic multiply-add term: the split tower computes a_hi w_hi + a_lo w_hi + a_hi w_lo
+MFMA_TERMS = {"f16x2": 3, "bf16": 1, "f32": 1}
+DTYPE_NOTE = {
+    "f16x2": "split precision: activations and weights as pairs of f16 values (22 significant bits), three f16 MFMA terms per product, "
+             "f32 accumulation, f32 heads; inside the reference's cross-runtime tolerance (training/tests/test_net_output.py:28-33)",
+    "bf16": "bf16 operands, f32 accumulation: throughput mode, 8 significant bits, outside the reference's tolerance",
+    "f32": "exact-f32 MFMA tower (v_mfma_f32_32x32x2_f32): bit-identical to the CPU oracle",
+}
+# node-evals/s one GPU sustains per dtype (sizes the bounded self-play samples; measured round 3)
+EVAL_CAPACITY = {"f16x2": 135e3, "bf16": 330e3, "f32": 44e3}
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
@@ -103,13 +118,53 @@ def cpu_baseline(blob, planes, budget_s: float = 12.0):
     dt = timed(n, cores)
     n = int(min(len(planes), max(cores, (budget_s * n / dt) // cores * cores)))
     dt = timed(n, cores)
+    oracle_entry = {"value": n / dt, "cores": cores, "kind": "port", "what": "oracle/oracle_net.c: plain C restatement of the f32 arithmetic, OpenMP over leaves",
+                    "one_thread": n1 / dt1, "sample": f"{n} leaves on {cores} threads in {dt:.1f} s; {n1} leaves on one thread in {dt1:.1f} s"}
+    # The same network as a plain torch module on the CPU (cattus_amd/torch_model.py: this repository's own module with the
+    # reference checkpoint's key names; fp32, oneDNN convolutions) -- the fair CPU evaluator figure: a tuned CPU library, not a
+    # scalar port.  The reference's own runtimes (ORT / tract / ExecuTorch) are not in this image.
+    torch_entry = None
+    try:
+        import torch
+
+        from cattus_amd.torch_model import PolicyValueNet
+
+        d = PolicyValueNet.from_blob(blob).desc
+        tnet = PolicyValueNet.from_blob(blob)
+        bits = np.unpackbits(planes.view(np.uint8).reshape(len(planes), d.planes, -1), axis=-1, bitorder="little")
+        x = torch.from_numpy(bits[..., : d.hw].reshape(len(planes), d.planes, d.board, d.board).astype(np.float32))
+        old_threads = torch.get_num_threads()
+
+        def ttimed(nn_, threads, reps=1):
+            torch.set_num_threads(threads)
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    tnet(x[:nn_])
+                return time.perf_counter() - t0
+
+        ttimed(min(len(x), 2 * cores), cores)  # warm-up: oneDNN primitive creation, thread pool
+        nt = len(x)  # whole bench batches, repeated until the sample costs about budget_s
+        tdt = ttimed(nt, cores)
+        reps = int(max(1, min(200, budget_s * 0.8 / tdt)))
+        tdt = ttimed(nt, cores, reps)
+        nt *= reps
+        ttimed(1, 1)
+        nt1 = int(max(1, min(64, 3.0 / max(ttimed(1, 1), 1e-3))))
+        tdt1 = ttimed(nt1, 1)
+        torch.set_num_threads(old_threads)
+        torch_entry = {"value": nt / tdt, "cores": cores, "kind": "port", "what": f"cattus_amd/torch_model.py on torch {torch.__version__} CPU (fp32, oneDNN)",
+                       "one_thread": nt1 / tdt1, "sample": f"{nt} leaves in batches of {len(x)} on {cores} threads in {tdt:.1f} s; {nt1} leaves on one thread in {tdt1:.1f} s"}
+    except Exception as exc:  # noqa: BLE001 - the baseline is a report, not the product
+        torch_entry = {"error": repr(exc)}
+    best = max([e for e in (oracle_entry, torch_entry) if e and "value" in e], key=lambda e: e["value"])
     out = {
-        "value": n / dt,
+        "value": best["value"],
         "unit": "node-evals/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n} of the {len(planes)} bench leaves, oracle/oracle_net.c f32 on {cores} threads, {dt:.1f} s",
-        "evaluator": {"value": n / dt, "cores": cores, "one_thread": n1 / dt1, "one_thread_sample": f"{n1} leaves, {dt1:.1f} s"},
+        "sample": best["what"] + ": " + best["sample"],
+        "evaluator": {"oracle_c": oracle_entry, "torch_cpu": torch_entry},
     }
 
     # ---- the path: search + network, one search thread per CPU, each blocking on its own leaf (batch_size 1)
@@ -188,7 +243,8 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
         "peak": 8000.0,
         "unit": "GB/s",
         "frac": achieved / 8000.0,
-        "traffic": measured_traffic("planes_to_tensor_nchw64_kernel"),
+        "traffic": measured_traffic("planes_to_tensor_nchw64_kernel", "any")[0],
+        "traffic_source": measured_traffic("planes_to_tensor_nchw64_kernel", "any")[1],
         "avg_launch_us": us,
         "leaves_per_launch": leaves,
         "bytes_per_leaf": 4752,
@@ -197,18 +253,39 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
     }
 
 
-def measured_traffic(kernel: str):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC pass (profiles/), or None."""
-    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
-        try:
-            with open(ROOT / "profiles" / name) as f:
-                return json.load(f)[kernel]["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+TRAFFIC_FILE = "profiles/r03_pmc_hbm_traffic.json"
+
+
+def kernels_sha256() -> str:
+    """Identity of the kernel source the traffic counters were collected on."""
+    return hashlib.sha256((ROOT / "cattus_amd" / "csrc" / "kernels.hip").read_bytes()).hexdigest()
+
+
+def measured_traffic(kernel: str, dtype: str = "f16x2"):
+    """(HBM-side bytes per launch, where they come from) from the committed rocprofv3 PMC passes (separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction: scripts/collect_profiles.sh + scripts/make_traffic_json.py).
+    The counters cannot be collected inside this process, so the file carries the sha256 of kernels.hip it was
+    collected on: when the kernels have changed since, the figure is withheld (None) rather than reported stale."""
+    try:
+        with open(ROOT / TRAFFIC_FILE) as f:
+            t = json.load(f)
+        entry = t["by_dtype"][dtype][kernel]
+    except (OSError, KeyError, ValueError):
+        return None, f"no PMC pass for this kernel / dtype in {TRAFFIC_FILE}"
+    if t.get("kernels_sha256") != kernels_sha256():
+        return None, f"withheld: {TRAFFIC_FILE} was collected on another version of kernels.hip (re-run scripts/collect_profiles.sh)"
+    return entry["traffic_bytes_per_launch"], f"{TRAFFIC_FILE} (rocprofv3 --pmc passes, commit {t.get('commit', '?')}, same kernels.hip)"
 
 
 # ------------------------------------------------------------------------------------------ self-play legs
+
+
+def search_threads(sp, world: int) -> int:
+    """Search threads of one rank: its CPU share (the cgroup quota split over the ranks, or -- once cattus_amd.affinity
+    has pinned the rank -- its own mask) minus room for the two evaluation threads, the HIP runtime's threads and the
+    main thread (15 search threads on a 16-CPU share starved them: 261 k vs 337 k node-evals/s)."""
+    share = min(sp.available_cpus() // max(1, min(world, 8)), len(os.sched_getaffinity(0)))
+    return max(1, share - 4)
 
 
 def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, max_game_plies, keep_records, pool, torch, dev):
@@ -222,7 +299,7 @@ def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, ma
 
     # search threads: the CPU share of this rank minus room for the two evaluation threads, the HIP runtime's
     # threads and the main thread (15 search threads on a 16-CPU share starved them: 261 k vs 337 k node-evals/s)
-    threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 4)
+    threads = search_threads(sp, world)
     with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
         cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
                              first_game=rank, game_stride=world, seed=1, max_game_plies=max_game_plies,
@@ -258,9 +335,14 @@ def reduce_leg(leg, torch, dev, world):
     t = torch.tensor([leg["seconds"], leg["games"], leg["node_evals"], leg["batches"], leg["positions"], leg["steady_rate"],
                       leg["adjudicated"], leg["pool_seconds"], leg["cache_hits"]], dtype=torch.float64, device=dev)
     tmax = t.clone()
+    per_rank = [leg["node_evals"] / max(leg["seconds"], 1e-9)]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        mine = torch.tensor(per_rank, dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x.item()) for x in allr]
     secs = float(tmax[0].item())
     games, evals, batches, plies = (float(t[i].item()) for i in (1, 2, 3, 4))
     out = {
@@ -278,6 +360,10 @@ def reduce_leg(leg, torch, dev, world):
         "concurrent_games_per_gpu": leg["slots"],
         "host_threads_per_gpu": leg["threads"],
         "seconds": secs,
+        # what the collectives saw: the process group's size and backend, and every rank's own rate
+        "ranks": dist.get_world_size() if dist.is_initialized() else 1,
+        "collective_backend": dist.get_backend() if dist.is_initialized() else None,
+        "node_evals_per_sec_per_rank": per_rank,
     }
     return out
 
@@ -290,16 +376,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--dtype", choices=["f16x2", "bf16", "f32"], default="f16x2", help="tower of the headline `value` (default: the split-precision tower)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="chess20x256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, choices=[1, 2], default=2,
                     help="2 = also time the K steps with two batches in flight (extra object; `value` stays single-stream)")
     ap.add_argument("--selfplay-seconds", type=float, default=40.0, help="time budget of the 800-sim self-play leg (0 = skip all self-play legs)")
     ap.add_argument("--selfplay-sims", type=int, default=800, help="simulations per move of the end-to-end leg (BASELINE config 3: 800)")
-    ap.add_argument("--agreement-plies", type=int, default=4, help="searched plies per game of the bf16-vs-f32 search agreement leg (0 = skip)")
-    ap.add_argument("--no-f32", action="store_true", help="skip the f32 (reference precision) object")
-    ap.add_argument("--no-long-run", action="store_true", help="skip the extra 400-step measurement")
+    ap.add_argument("--agreement-plies", type=int, default=4, help="searched plies per game of the search agreement leg (0 = skip)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32 (bit-exact) object")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 (throughput mode) object")
+    ap.add_argument("--settle-seconds", type=float, default=0.4,
+                    help="untimed steps run for this long IN FRONT of the W warm-up steps (the clock governor needs longer than W steps to settle); 0 = none")
     args = ap.parse_args()
 
     import torch
@@ -307,6 +395,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the leaf evaluator has no CPU path")
     # Rehearsal of the N > 1 code path on a box with one GPU (never for a quoted number): BENCH_REHEARSAL=1 puts
@@ -314,6 +403,12 @@ def main():
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    # one process per GPU: a disjoint share of the host's CPUs for this rank, on its GPU's NUMA node where sysfs tells
+    # (before any thread of the evaluator or the search exists; cattus_amd/affinity.py)
+    from cattus_amd import affinity
+
+    cpu_share = affinity.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), local_world,
+                                  None if rehearsal else affinity.torch_pci_bus_ids(local_world) if local_world > 1 else None)
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
@@ -350,8 +445,9 @@ def main():
             return float(t.item())
         return x
 
-    def time_evaluator(dtype, steps, warmup, lanes=1):
-        """-> (seconds for `steps` steps, max over ranks; event-stamped tower launch µs; launches per step; outputs)"""
+    def time_evaluator(dtype, steps, warmup, lanes=1, settle_s=0.0):
+        """K steps of the hot path on the `dtype` tower -> dict(elapsed = seconds for the K steps (max over ranks),
+        launch_us = event-stamped tower launch duration, launches per step, ...)."""
         ev = HipEvaluator(blob, batch_size=batch, plane_words=plane_words, dtype=dtype, device=local_rank)
         d_policy = torch.empty((batch, d.moves), dtype=torch.float32, device=dev)
         d_value = torch.empty((batch,), dtype=torch.float32, device=dev)
@@ -359,18 +455,23 @@ def main():
         def step():
             ev.eval_device(d_planes.data_ptr(), batch, d_policy.data_ptr(), d_value.data_ptr(), stream.cuda_stream)
 
-        # The same measurement over 400 steps, FIRST: the driver times 20 steps behind 5 warm-up steps, i.e. 20 ms after
-        # the process touched the GPU for the first time, and the clock governor needs longer than that to settle (on
-        # one box: 322 k node-evals/s in that window, 359 k over the 400 steps that followed it).  With this run in
-        # front, the W warm-up steps and the K timed steps below see the device in its steady state.
-        long_ms = None
-        if dtype == "bf16" and steps < 400 and not args.no_long_run:
+        # Settling run, untimed, in FRONT of the W warm-up steps: the driver times 20 steps behind 5 warm-up steps, i.e.
+        # a few tens of milliseconds after the process touched the GPU for the first time, and the clock governor needs
+        # longer than that (round 2: 322 k node-evals/s in that window, 359 k over the 400 steps behind it).  It is
+        # reported (`effective_warmup_steps`, `settle`), and its own rate is in the line for comparison.
+        settle_steps, settle_ms = 0, None
+        if settle_s > 0:
             sync_all()
             t0 = time.perf_counter()
-            for _ in range(400):
-                step()
+            while True:
+                for _ in range(20):
+                    step()
+                settle_steps += 20
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0 >= settle_s:
+                    break
             sync_all()
-            long_ms = max_over_ranks(time.perf_counter() - t0) / 400 * 1e3
+            settle_ms = max_over_ranks(time.perf_counter() - t0) / settle_steps * 1e3
         for _ in range(warmup):
             step()
         sync_all()
@@ -383,7 +484,7 @@ def main():
         assert bool(torch.isfinite(d_policy).all()) and bool(torch.isfinite(d_value).all())
         # roofline of the dominant kernel (3x3 conv tower launch): event-stamped launch durations of the same
         # forward, taken right behind the timed region so that the device is in the same state as for `value`
-        launch_us, launches = ev.time_tower(batch, 20) if rank == 0 else (0.0, 1)
+        launch_us, launches = ev.time_tower(batch, 20 if dtype != "f32" else 5) if rank == 0 else (0.0, 1)
         elapsed2 = None
         if lanes == 2:
             # the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
@@ -410,46 +511,60 @@ def main():
             elapsed2 = max_over_ranks(time.perf_counter() - t0)
             assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
         ev.close()
-        return elapsed, launch_us, launches, elapsed2, "tower64_lds_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel", long_ms
+        return dict(elapsed=elapsed, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2,
+                    kernel="tower64_lds_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel", settle_steps=settle_steps, settle_ms=settle_ms)
 
-    def roofline(dtype, launch_us, launches, kernel):
-        flop_per_launch = d.conv_flops_per_position() * batch / launches
-        achieved = flop_per_launch / (launch_us * 1e-6) / 1e12
+    def roofline(dtype, r):
+        """Dominant kernel = the tower conv launch.  `achieved` counts ALGORITHMIC flops (2 x multiply-adds of the
+        network: SURVEY.md section 8d) per launch over the launch's measured duration; `peak` is the dense MFMA peak of
+        the operand type the kernel issues.  The split tower issues 3 MFMA terms per algorithmic multiply-add, so the
+        share of the matrix pipe it keeps busy is 3 x frac (`mfma_pipe_frac`)."""
+        flop_per_launch = d.conv_flops_per_position() * batch / r["launches"]
+        achieved = flop_per_launch / (r["launch_us"] * 1e-6) / 1e12
         peak = MFMA_PEAK_TFLOPS[dtype]
+        traffic, source = measured_traffic(r["kernel"], dtype) if headline else (None, "collected for the headline workload only")
         return {
-            "kernel": kernel,
+            "kernel": r["kernel"],
             "bound": "mfma",
             "achieved": achieved,
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": achieved / peak,
-            "traffic": measured_traffic(kernel) if headline and dtype == "bf16" else None,
-            "avg_launch_us": launch_us,
-            "launches_per_step": launches,
+            "traffic": traffic,
+            "traffic_source": source,
+            "avg_launch_us": r["launch_us"],
+            "launches_per_step": r["launches"],
             "flop_per_launch": flop_per_launch,
+            "mfma_terms_per_multiply_add": MFMA_TERMS[dtype],
+            "mfma_pipe_frac": MFMA_TERMS[dtype] * achieved / peak,
+            "peak_of": "f16 / bf16 32x32x16 MFMA, dense" if dtype != "f32" else "f32 32x32x2 MFMA",
         }
 
-    elapsed, launch_us, launches, elapsed2, kname, long_ms = time_evaluator(args.dtype, args.steps, args.warmup, args.lanes)
-    kname = kname or "conv3x3_mfma_v2_kernel"
+    def side_object(dtype, r):
+        return {
+            "value": world * batch * r["steps"] / r["elapsed"],
+            "unit": "node-evals/s",
+            "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
+            "steps": r["steps"],
+            "dtype": dtype,
+            "note": DTYPE_NOTE[dtype],
+            "roofline": roofline(dtype, r),
+        }
 
-    f32_out = None
-    if args.dtype == "bf16" and not args.no_f32:
-        steps32 = max(5, args.steps // 10)
-        e32, us32, l32, _, k32, _ = time_evaluator("f32", steps32, max(2, args.warmup // 10))
+    main_r = time_evaluator(args.dtype, args.steps, args.warmup, args.lanes, args.settle_seconds)
+
+    sides = {}
+    for dtype, skip, div in (("bf16", args.no_bf16, 1), ("f32", args.no_f32, 10)):
+        if dtype == args.dtype or skip:
+            continue
+        k = max(5, args.steps // div)
+        r = time_evaluator(dtype, k, max(2, args.warmup // div), settle_s=0.2 if dtype == "bf16" else 0.0)
         if rank == 0:
-            f32_out = {
-                "value": world * batch * steps32 / e32,
-                "unit": "node-evals/s",
-                "ms_per_step": e32 / steps32 * 1e3,
-                "steps": steps32,
-                "dtype": "f32",
-                "note": "exact-f32 MFMA tower (v_mfma_f32_32x32x2_f32): the reference's precision, bit-identical to the CPU oracle",
-                "roofline": roofline("f32", us32, l32, k32 or "conv3x3_mfma_v2_kernel"),
-            }
+            sides[dtype] = side_object(dtype, r)
 
-    # ---- bf16 vs f32 at SEARCH level (rank 0): 800-sim searches of the same positions with both towers
+    # ---- reduced-cost towers vs f32 at SEARCH level (rank 0): 800-sim searches of the same positions with each tower
     agreement = None
-    if headline and args.dtype == "bf16" and args.agreement_plies > 0 and rank == 0:
+    if headline and args.agreement_plies > 0 and rank == 0 and args.dtype != "f32":
         from cattus_amd import agreement as ag
         from cattus_amd import selfplay as sp
 
@@ -460,51 +575,54 @@ def main():
             opens = ag.random_openings("chess", games, 2, seed=7)
             ta = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev32), opens, 2, args.agreement_plies)
         lines = [op + [c for c, _ in t] for op, t in zip(opens, ta)]
-        with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="bf16", device=local_rank, flush_us=100) as ev16:
-            tb = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev16), lines, 2, args.agreement_plies)
-        agreement = ag.compare_traces(ta, tb)
+        agreement = {}
+        for dtype in [args.dtype] + ([] if args.no_bf16 or args.dtype == "bf16" else ["bf16"]):
+            with HipEvaluator(blob, batch_size=games, plane_words=1, dtype=dtype, device=local_rank, flush_us=100) as evx:
+                tb = ag.run_traces("chess", cfg, sp.Net.hip_batched(evx), lines, 2, args.agreement_plies)
+            agreement[dtype] = ag.compare_traces(ta, tb)
         agreement.update(games=games, sims_per_move=800, searched_plies_per_game=args.agreement_plies, seconds=time.perf_counter() - t0,
-                         note="f32 plays; bf16 searches the same positions (teacher-forced, trees carried over); greedy move choice, noise off. "
-                              "tests/test_search_parity_gpu.py runs 16 plies per game and bounds these numbers")
+                         note="f32 plays; each tower searches the same positions (teacher-forced, trees carried over); greedy move choice, noise "
+                              "off. tests/test_search_parity_gpu.py runs 16 plies per game and bounds these numbers; larger samples: "
+                              "profiles/r03_search_agreement_*.json")
 
     # ---- end-to-end self-play legs (all ranks; each plays its own shard of the games)
     sp_out = sp_full = sp_c4 = None
     if headline and args.selfplay_seconds > 0:
         from cattus_amd import selfplay as sp
 
-        threads = max(1, sp.available_cpus() // max(1, min(world, 8)) - 4)
+        threads = search_threads(sp, world)
         # BASELINE config 3 as written: 800 sims/move, batch 256; 1536 concurrent games (two batches in flight and four
-        # more in the making: with 1024 the two lanes are busy 76 % of the time each, with 1536 95 %, +4 % throughput);
-        # every game is cut after `plies` plies so that the leg fits its time budget (a whole 800-sim game of ~290 plies
-        # costs ~170 k evaluations, 1536 of them ~13 minutes of GPU time)
-        capacity = min(330e3, threads * 60e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
+        # more in the making); every game is cut after `plies` plies so that the leg fits its time budget (a whole
+        # 800-sim game of ~290 plies costs ~170 k evaluations)
+        capacity = min(EVAL_CAPACITY[args.dtype], threads * 60e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
         conc = 1536
-        plies = int(max(4, min(64, args.selfplay_seconds * capacity / (conc * 0.75 * args.selfplay_sims))))
+        plies = int(max(3, min(64, args.selfplay_seconds * capacity / (conc * 0.75 * args.selfplay_sims))))
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=conc, slots=conc, sims=args.selfplay_sims, max_game_plies=plies,
                            keep_records=False, pool=False, torch=torch, dev=cdev)
         sp_out = reduce_leg(leg, torch, cdev, world)
-        sp_out.update(max_game_plies=plies, settings=SELFPLAY_SETTINGS_TEXT,
+        sp_out.update(max_game_plies=plies, settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype,
                       note="bounded sample: every game is adjudicated after max_game_plies plies; games_per_hour_estimate = plies_per_sec "
-                           "* 3600 / (plies per whole game measured in selfplay_full_games)")
+                           "* 3600 / (plies per whole game measured in selfplay_full_games) -- an ESTIMATE; measured whole games at 800 sims: "
+                           "profiles/r03_e2e_whole_games_800sims.json")
         # whole games, reduced simulation count: a measured games/hour
         full_sims = 64
         full_games = int(min(1024, max(64, 25.0 * capacity / (190.0 * full_sims)))) // 2 * 2
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=full_games, slots=full_games, sims=full_sims, max_game_plies=0,
                            keep_records=False, pool=False, torch=torch, dev=cdev)
         sp_full = reduce_leg(leg, torch, cdev, world)
-        sp_full.update(games_per_hour=sp_full["games"] * 3600.0 / sp_full["seconds"], settings=SELFPLAY_SETTINGS_TEXT)
+        sp_full.update(games_per_hour=sp_full["games"] * 3600.0 / sp_full["seconds"], settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype)
         sp_out["games_per_hour_estimate"] = sp_out["plies_per_sec"] * 3600.0 / max(1.0, sp_full["plies_per_game"])
         # BASELINE config 4's shape: 64 concurrent games per GPU (sequential search: at most 64 leaves per batch), records
         # kept and pooled over RCCL (all-gather) with the counters all-reduced, all inside the timed region
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=64, slots=64, sims=args.selfplay_sims, max_game_plies=6,
                            keep_records=True, pool=True, torch=torch, dev=cdev)
         sp_c4 = reduce_leg(leg, torch, cdev, world)
-        sp_c4.update(max_game_plies=6, pool_seconds=leg["pool_seconds"], pooled=leg["pooled"], settings=SELFPLAY_SETTINGS_TEXT,
+        sp_c4.update(max_game_plies=6, pool_seconds=leg["pool_seconds"], pooled=leg["pooled"], settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype,
                      note="64 games per GPU, records all-gathered and counters all-reduced through torch.distributed 'nccl' (= RCCL) inside "
                           "the timed region; one leaf per tree in flight, so a batch holds at most 64 leaves")
 
     if rank == 0:
-        value = world * batch * args.steps / elapsed
+        value = world * batch * args.steps / main_r["elapsed"]
         out = {
             "metric": "MCTS node-evals/sec (chess 20x256 net, batch 256)",
             "value": value,
@@ -512,39 +630,42 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": main_r["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
+            "dtype_note": DTYPE_NOTE[args.dtype],
             "data": "synthetic leaf positions + seeded random-init weights",
             "config": {
                 "workload": f"{args.workload}: ConvNetV1 {d.blocks}x{d.filters}, board {d.board}, "
-                f"{d.planes} planes, {d.moves} moves, batch {batch} leaves/GPU, evaluator-only",
+                f"{d.planes} planes, {d.moves} moves, batch {batch} leaves/GPU, evaluator-only (planes, logits and values resident in HBM: "
+                "no PCIe, no search; the rate with both is `selfplay.node_evals_per_sec`)",
                 "per_gpu_batch": batch,
                 "flop_per_leaf": d.flops_per_position(),
             },
             "per_gpu_value": value / world,
-            "roofline": roofline(args.dtype, launch_us, launches, kname),
+            "effective_warmup_steps": args.warmup + main_r["settle_steps"],
+            "roofline": roofline(args.dtype, main_r),
+            "host": {"cpus_of_this_rank": len(cpu_share), "ranks_on_this_node": local_world},
         }
-        out["whole_step_mfma_frac"] = d.flops_per_position() * batch / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype]
-        if f32_out is not None:
-            out["f32"] = f32_out
+        out["whole_step_mfma_frac"] = d.flops_per_position() * batch / (main_r["elapsed"] / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype]
+        if main_r["settle_ms"] is not None:
+            out["settle"] = {"steps": main_r["settle_steps"], "ms_per_step": main_r["settle_ms"], "value": world * batch / (main_r["settle_ms"] * 1e-3),
+                             "note": "untimed steps in front of the W warm-up steps (clock governor); their own rate, for comparison with `value`"}
+        if main_r["elapsed2"] is not None:
+            out["two_batches_in_flight"] = {
+                "value": batch * world * args.steps / main_r["elapsed2"],
+                "ms_per_step": main_r["elapsed2"] / args.steps * 1e3,
+                "note": "same K steps alternating between the evaluator's two lanes on two streams",
+            }
+        out.update(sides)
         if agreement is not None:
-            out["bf16_search_agreement"] = agreement
+            out["search_agreement"] = agreement
         if headline:
             from cattus_amd import evaluator as ev_mod
 
             out["roofline_plane_pack"] = pack_roofline(torch, ev_mod.load_library(), dev, stream)
-        if long_ms is not None:
-            out["same_over_400_steps"] = {"value": world * batch / (long_ms * 1e-3), "ms_per_step": long_ms,
-                                          "note": "run before the W warm-up steps and the K timed steps of `value` (settles the clock governor)"}
-        if elapsed2 is not None:
-            out["two_batches_in_flight"] = {
-                "value": batch * world * args.steps / elapsed2,
-                "ms_per_step": elapsed2 / args.steps * 1e3,
-                "note": "same K steps alternating between the evaluator's two lanes on two streams",
-            }
         if sp_out is not None:
             out["selfplay"], out["selfplay_full_games"], out["selfplay_config4"] = sp_out, sp_full, sp_c4
         if world == 1 and not args.no_cpu_baseline:

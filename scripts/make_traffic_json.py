@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""profiles/rNN_pmc_hbm_traffic.json from the per-dtype PMC summaries of scripts/collect_profiles.sh:
+    python scripts/make_traffic_json.py gpurun_out/TAG > profiles/r03_pmc_hbm_traffic.json
+The file carries the sha256 of cattus_amd/csrc/kernels.hip the passes ran on; bench.py withholds the traffic figure
+when the kernels have changed since (it cannot collect PMC counters inside its own process)."""
+import hashlib
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = Path(sys.argv[1])
+# algorithmic HBM-side bytes per launch, chess 20x256 at batch 256, averaged over the 41 launches of a step: per launch the
+# 16384 x 256 activations in and out (+ the skip rows in 20 of them) at the dtype's bytes per channel, the layer's weights once
+ACT = 16384 * 256
+ALG = {}
+for dtype, abytes, wbytes in (("bf16", 2, 2), ("f16x2", 4, 4), ("f32", 4, 4)):
+    w = 9 * 256 * 256 * wbytes
+    stem = 256 * 144 + 9 * 256 * (64 if dtype == "bf16" else 32) * wbytes + ACT * abytes
+    ALG[dtype] = (stem + 20 * (2 * ACT * abytes + w) + 20 * (3 * ACT * abytes + w)) / 41
+out = {
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/collect_profiles.sh) -- python3 bench.py --dtype D --steps 5 "
+              "--warmup 2 --lanes 1 --settle-seconds 0 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32 --no-bf16, MI355X",
+    "units": "FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read, so fetched bytes = "
+             "2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section). Fabric-side L2 requests: Infinity Cache hits are included.",
+    "kernels_sha256": hashlib.sha256((ROOT / "cattus_amd" / "csrc" / "kernels.hip").read_bytes()).hexdigest(),
+    "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
+    "by_dtype": {},
+}
+for dtype in ("f16x2", "bf16", "f32"):
+    f = tag / f"pmc_summary_{dtype}.json"
+    if not f.exists():
+        continue
+    summ = json.loads(f.read_text())
+    entry = {}
+    for k, v in summ.items():
+        if "traffic_bytes_per_launch" not in v:
+            continue
+        name = k.replace("cattus::", "")
+        entry[name] = {"traffic_bytes_per_launch": v["traffic_bytes_per_launch"]}
+        if name == "conv3x3_mfma_v2_kernel":
+            entry[name]["algorithmic_bytes_per_launch"] = int(ALG[dtype])
+    out["by_dtype"][dtype] = entry
+    if "planes_to_tensor_nchw64_kernel" in entry:
+        out["by_dtype"].setdefault("any", {})["planes_to_tensor_nchw64_kernel"] = dict(entry["planes_to_tensor_nchw64_kernel"], algorithmic_bytes_per_launch=262144 * 4752)
+json.dump(out, sys.stdout, indent=1)
