@@ -28,13 +28,15 @@
 #include "../../include/cattus_hip.h"
 #include "kernels.h"
 
-// Kernel arguments in device memory.  By default the HIP runtime keeps the kernel-argument ring in host memory and the
-// command processor fetches every launch's arguments over the host link before the first wave starts: ~1.6 us per
-// launch, 8 % of a 41-launch forward pass (profiles/r02_experiments.txt).  The runtime reads the switch once, when it
-// initialises, so it is set when this library is loaded -- in a host where this library is the first HIP user (the
-// reference's self-play binary) that is early enough; a host that initialises HIP itself sets it in its environment
-// (bench.py and cattus_amd/__init__.py do).  An explicit setting in the environment wins.
-__attribute__((constructor)) static void cattus_hip_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+// Kernel arguments in device memory: by default the HIP runtime keeps the kernel-argument ring in host memory and the
+// command processor fetches every launch's arguments over the host link before the first wave starts (~1.6 us per
+// launch, 8 % of a 41-launch bf16 forward pass; profiles/r02_experiments.txt).  HIP_FORCE_DEV_KERNARG=1 moves the ring
+// into HBM, but the runtime reads it once, when it initialises, and the variable belongs to the HOST process: this
+// library does not touch the environment (a library constructor calling setenv races with the host's threads and
+// changes the runtime for every other HIP user).  bench.py, the tests, the Python package (opt-out: CATTUS_NO_ENV_DEFAULTS=1)
+// and bin/*_self_player export it; INTEGRATION.md tells a Rust host to do the same.  cattus_hip_create reports the
+// setting it found in cattus_hip_runtime_note().
+static std::string g_runtime_note;
 
 using namespace cattus;
 
@@ -722,7 +724,8 @@ void server_loop(cattus_eval* e) {
 // ------------------------------------------------------------------------------------------ ABI
 
 CATTUS_API const char* cattus_hip_last_error(void) { return g_last_error.c_str(); }
-CATTUS_API const char* cattus_hip_version(void) { return "cattus_hip 0.1 (gfx950)"; }
+CATTUS_API const char* cattus_hip_version(void) { return "cattus_hip 0.2 (gfx950)"; }
+CATTUS_API const char* cattus_hip_runtime_note(void) { return g_runtime_note.c_str(); }
 
 CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattus_eval_config* cfg, cattus_eval** out) {
     if (!out) return fail(CATTUS_E_INVALID, "out is NULL");
@@ -764,6 +767,14 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
         }
     }
     // every environment switch is read here, once per evaluator: nothing on the evaluation path calls getenv
+    {
+        static std::mutex note_mu;
+        std::lock_guard<std::mutex> lk(note_mu);
+        const char* ka = getenv("HIP_FORCE_DEV_KERNARG");
+        g_runtime_note = ka && ka[0] == '1' ? "HIP_FORCE_DEV_KERNARG=1: kernel arguments in device memory"
+                                            : "HIP_FORCE_DEV_KERNARG is not 1: kernel arguments travel over the host link (about +8 % per batch); "
+                                              "export HIP_FORCE_DEV_KERNARG=1 before the process initialises HIP";
+    }
     const char* wait_mode = getenv("CATTUS_HIP_WAIT");
     set_conv_cb(getenv("CATTUS_CONV_CB") ? atoi(getenv("CATTUS_CONV_CB")) : 0);
     const char* fused_stem_env = getenv("CATTUS_FUSED_STEM");

@@ -103,13 +103,13 @@ class EvalCache {
         }
         // "remove the oldest while len >= max_size, then insert" (cache.rs:62-70): after either order of the two
         // steps the cache holds the newest max_size positions
-        typename G::Position victim;
+        typename G::Position victim, entry = pos;  // copied outside the lock, moved in under it
         bool evict = false;
         {
             SpinGuard g(fifo_lock_);
-            fifo_.push_back(pos);
+            fifo_.push_back(std::move(entry));
             if (fifo_.size() > max_size_) {
-                victim = fifo_.front();
+                victim = std::move(fifo_.front());
                 fifo_.pop_front();
                 evict = true;
             }
@@ -135,8 +135,20 @@ class EvalCache {
    private:
     struct SpinGuard {
         std::atomic_flag& f;
+        // held for one push / pop: spin briefly, then give the core away (with more search threads than CPUs the holder
+        // may be descheduled, and spinning through its whole quantum would be the convoy this lock replaced)
         explicit SpinGuard(std::atomic_flag& fl) : f(fl) {
-            while (f.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause();
+            for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); spins++) {
+                if (spins < 128) cpu_relax();
+                else std::this_thread::yield();
+            }
+        }
+        static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#elif defined(__aarch64__)
+            asm volatile("yield");
+#endif
         }
         ~SpinGuard() { f.clear(std::memory_order_release); }
     };

@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "cattus_hip_planes_to_tensor_device",
     "cattus_hip_last_error",
     "cattus_hip_version",
+    "cattus_hip_runtime_note",
 ]
 
 
@@ -122,9 +123,10 @@ def load_library():
     L.cattus_hip_planes_to_tensor_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.cattus_hip_last_error.restype = C.c_char_p
     L.cattus_hip_version.restype = C.c_char_p
+    L.cattus_hip_runtime_note.restype = C.c_char_p
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("cattus_hip_last_error", "cattus_hip_version", "cattus_hip_host_alloc"):
+        if fn.restype is C.c_int and name not in ("cattus_hip_last_error", "cattus_hip_version", "cattus_hip_runtime_note", "cattus_hip_host_alloc"):
             fn.restype = C.c_int
     _lib = L
     return L

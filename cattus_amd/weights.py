@@ -164,6 +164,30 @@ def blob_from_state_dict(d: NetDesc, state_dict) -> bytes:
     return pack_tensors(d, tensors)
 
 
+def desc_from_state_dict(state_dict, board: int) -> NetDesc:
+    """The network's shape read off a ConvNetV1 ``state_dict`` (net_utils.py:45-89): planes / filters from the stem conv,
+    blocks from the residual keys, head widths and move count from the head layers."""
+    shape = lambda k: tuple(state_dict[k].shape)  # noqa: E731
+    filters, planes = shape("_conv1._conv.weight")[:2]
+    blocks = 0
+    while f"_residual_blocks.{blocks}._conv1.weight" in state_dict:
+        blocks += 1
+    vhc, phc = shape("_value_head.0._conv.weight")[0], shape("_policy_head.0._conv.weight")[0]
+    moves = shape("_policy_head.2.weight")[0]
+    d = NetDesc(planes, board, moves, blocks, filters, vhc, phc)
+    if shape("_policy_head.2.weight")[1] != phc * d.hw or shape("_value_head.2.weight") != (FC_HIDDEN, vhc * d.hw):
+        raise ValueError("state_dict does not belong to a ConvNetV1 on a %dx%d board" % (board, board))
+    return d
+
+
+def blob_from_module(model, input_shape) -> bytes:
+    """What the trainer's ``export_model`` calls for the ``hip`` engine (integration/rust/cattus_hip.patch,
+    training/cattus_train/self_play.py): the module's ``state_dict`` as an evaluator blob.  ``input_shape`` is the
+    (1, planes, S, S) tuple the trainer passes around (train_process.py:381-383)."""
+    sd = model.state_dict()
+    return blob_from_state_dict(desc_from_state_dict(sd, int(input_shape[-1])), sd)
+
+
 def state_dict_from_blob(blob: bytes):
     """Inverse of :func:`blob_from_state_dict`; values are torch tensors."""
     import torch

@@ -149,6 +149,9 @@ int cattus_hip_planes_to_tensor_device(const uint64_t* d_planes, uint32_t n, uin
 
 const char* cattus_hip_last_error(void);
 const char* cattus_hip_version(void);
+/* What the last cattus_hip_create found for HIP_FORCE_DEV_KERNARG (the host process exports it before HIP initialises:
+ * kernel arguments in device memory, -8 % per batch; the library never changes the environment itself). */
+const char* cattus_hip_runtime_note(void);
 
 #ifdef __cplusplus
 }

@@ -48,23 +48,29 @@ def test_hip_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.cattus_hip_version()
 
 
-def test_loading_the_hip_library_defaults_kernel_arguments_to_device_memory():
-    """libcattus_hip.so asks the HIP runtime for a device-memory kernel-argument ring (HIP_FORCE_DEV_KERNARG=1, read when
-    the runtime initialises) from a load-time constructor, without overriding the environment."""
+def test_the_native_library_leaves_the_environment_alone_and_the_package_default_is_opt_out():
+    """HIP_FORCE_DEV_KERNARG (kernel arguments in device memory) belongs to the host process: loading
+    libcattus_hip.so must not change the environment (no setenv from a library constructor); `import cattus_amd` sets the
+    default unless CATTUS_NO_ENV_DEFAULTS=1, and never overrides an explicit value."""
+    import os
     import subprocess
     import sys
 
     from cattus_amd import evaluator
 
-    lib = str(evaluator.library_path()) if hasattr(evaluator, "library_path") else evaluator.load_library()._name
-    code = ("import ctypes, sys; ctypes.CDLL(sys.argv[1]); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
-            "print((libc.getenv(b'HIP_FORCE_DEV_KERNARG') or b'unset').decode())")
-    import os
+    lib = evaluator.load_library()._name
+    getenv = ("libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+              "print((libc.getenv(b'HIP_FORCE_DEV_KERNARG') or b'unset').decode())")
+    env = {k: v for k, v in os.environ.items() if k not in ("HIP_FORCE_DEV_KERNARG", "CATTUS_NO_ENV_DEFAULTS")}
 
-    env = {k: v for k, v in os.environ.items() if k != "HIP_FORCE_DEV_KERNARG"}
-    assert subprocess.run([sys.executable, "-c", code, lib], env=env, capture_output=True, text=True, check=True).stdout.strip() == "1"
-    env["HIP_FORCE_DEV_KERNARG"] = "0"
-    assert subprocess.run([sys.executable, "-c", code, lib], env=env, capture_output=True, text=True, check=True).stdout.strip() == "0"
+    def run(code, **extra):
+        return subprocess.run([sys.executable, "-c", "import ctypes, sys; " + code, lib], env=dict(env, **extra), capture_output=True, text=True,
+                              check=True, cwd=str(evaluator._PKG.parent)).stdout.strip()
+
+    assert run("ctypes.CDLL(sys.argv[1]); " + getenv) == "unset"
+    assert run("import cattus_amd; " + getenv) == "1"
+    assert run("import cattus_amd; " + getenv, CATTUS_NO_ENV_DEFAULTS="1") == "unset"
+    assert run("import cattus_amd; " + getenv, HIP_FORCE_DEV_KERNARG="0") == "0"
 
 
 # ------------------------------------------------------------------------------------------ ttt

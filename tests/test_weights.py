@@ -54,3 +54,13 @@ def test_flop_formula_matches_survey():
     assert W.NetDesc(**W.CHESS, blocks=20, filters=256, vhc=8, phc=8).flops_per_position() == 3027788032
     assert W.NetDesc(**W.hex_game(7), blocks=6, filters=64, vhc=16, phc=16).flops_per_position() == 43999904
     assert W.NetDesc(**W.CHESS, blocks=40, filters=384, vhc=8, phc=8).flops_per_position() == 13600350464
+
+
+def test_blob_from_module_infers_the_shape():
+    """export_model's hook for the hip engine: module -> blob, shape read off the state_dict."""
+    d = W.NetDesc(planes=3, board=7, moves=49, blocks=3, filters=16, vhc=16, phc=16)
+    net = PolicyValueNet.from_blob(W.seeded_blob(d, 3))
+    assert W.desc_from_state_dict(net.state_dict(), 7) == d
+    assert W.blob_from_module(net, (1, 3, 7, 7)) == W.seeded_blob(d, 3)
+    with pytest.raises(ValueError):
+        W.desc_from_state_dict(net.state_dict(), 5)
