@@ -273,28 +273,12 @@ struct StemPlanes<true> {
 //     (consumer wave: 1 x 2 tiles): twice the workgroups for the same layer, used while the full-size grid would
 //     leave more than half of the CUs empty (batches of <= 128 leaves on a 256-filter net).  Same MFMA shape and
 //     k order per output element, so the result does not depend on which of the two ran.
-// SPLIT (T = _Float16; K1s, the split-precision tower): every activation and every weight is a PAIR of f16 values,
-//     x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 significant bits), and a product is three MFMA terms,
-//     a_hi w_hi + a_lo w_hi + a_hi w_lo, accumulated in f32 (a_lo w_lo, 2^-22 of the product, is dropped).  The pairs
-//     are interleaved in groups of 32 channels: a 128-byte row piece is [hi of 32 channels | lo of the same 32], in
-//     `in` / `res` / `out` rows and in `w` rows alike, so a chunk carries 32 channels (as in the f32 kernel), the
-//     loaders, the LDS map and the swizzle are those of the other types, and a consumer stage (tap, 16 channels) reads
-//     the hi and lo fragments of both operands once (8 ds_read_b128) for its 12 MFMAs.  The stem's planes are 0/1
-//     (their lo half is zero).  Weights are pre-scaled per output channel by a power of two (so that their lo halves
-//     are normal f16 numbers); `bias` is followed by the cout inverse scales, applied (exactly) in the epilogue.
-//     flags & 1: the output is written as plain f32 [row][cout] instead of pairs (the last tower layer, for the f32
-//     head kernels).
-constexpr int CONV_OUT_F32 = 1;
-
-template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2, bool SPLIT = false>
+template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2>
 __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S, int flags,
-                           StemPlanes<STEM> sp) {
-    static_assert(!SPLIT || sizeof(T) == 2, "split precision runs on 2-byte operands");
+                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S, StemPlanes<STEM> sp) {
     static_assert(NLOAD == 4, "the stem expansion, the 32-cout tile and the piece counts below assume four loader waves");
-    constexpr int ESZ = SPLIT ? 4 : (int)sizeof(T);  // bytes of one channel of a row (SPLIT: hi + lo)
-    constexpr int KC = 128 / ESZ;         // channels per 128-byte chunk
+    constexpr int KC = 128 / (int)sizeof(T);
     constexpr int CPW = 32 * CB;          // output channels of this workgroup
     constexpr int WPLC = WPL * CB / 2;    // weight pieces per loader wave and step
     typedef typename Mfma<T>::frag frag;
@@ -319,7 +303,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 
     const int nch = cin / KC;
     const int T_total = nch * 3;
-    const uint32_t row_bytes = (uint32_t)cin * ESZ;
+    const uint32_t row_bytes = (uint32_t)cin * sizeof(T);
 
     if (is_loader) {
         // ================================ loader waves ================================
@@ -473,36 +457,21 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     // Epilogue operands that depend on nothing computed here are requested now, so their latency hides
     // under the main loop: the folded-BN bias of this lane's 8 cout quads, and (2-byte activations only,
     // for register budget) the skip-connection rows in the epilogue's (pixel row, 8 couts) layout.
+    f32x4 biasv[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
     // epilogue store layout: a pixel row of the tile is CPW couts = LPR lanes x 8 couts; 64 / LPR rows per trip
     constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = 64 / RPT;
     const int prow = lane / LPR, cg = lane % LPR;
-    // bias: in the accumulator's layout (added before the transpose), 16 CB registers; SPLIT keeps the bias and the
-    // inverse weight scale of the 8 couts the lane owns AFTER the transpose instead (16 registers for both)
-    f32x4 biasv[SPLIT ? 1 : CB][4], bias8[2], ds8[2];
-    if constexpr (SPLIT) {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            bias8[q] = *reinterpret_cast<const f32x4*>(bias + cout0 + cg * 8 + q * 4);
-            ds8[q] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cg * 8 + q * 4);
-        }
-    } else {
-#pragma unroll
-        for (int cb = 0; cb < CB; cb++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
-    }
     constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2;
-    // a row of `res` / `out` in elements of T, and where this lane's 8 couts start in it (SPLIT: the hi values of the
-    // 32-channel group, the lo values 32 elements further)
-    const size_t orow = (size_t)cout * (SPLIT ? 2 : 1);
-    const int ocol = SPLIT ? ((cout0 + cg * 8) >> 5) * 64 + ((cout0 + cg * 8) & 31) : cout0 + cg * 8;
-    T resv[EIT][SPLIT ? 16 : 8];
+    T resv[EIT][8];
     if (RES_EARLY) {
 #pragma unroll
         for (int i = 0; i < EIT; i++) {
-            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * orow + ocol;
+            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * (size_t)cout + cout0 + cg * 8;
             *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
-            if constexpr (SPLIT) reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(res + off + 32);
         }
     }
 
@@ -540,44 +509,6 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
                 }
-            if constexpr (SPLIT) {
-                // A stage is (tap, 16 channels): the hi and lo fragments of CB weight blocks and of 2 pixel blocks
-                // (slots ks = k and ks = 2 + k of the 128-byte rows) feed 3 x 2 CB MFMAs: hi hi, hi lo, lo hi.
-                constexpr int SA = 1, SR = SA + 1;  // stages of look-ahead (a stage is 384 cycles of MFMA issue), register ring
-                frag sah[SR][CB], sal[SR][CB], sbh[SR][2], sbl[SR][2];
-                auto load_split = [&](int i, int s) {
-                    const int dxi = i >> 1, k = i & 1;
-#pragma unroll
-                    for (int cb = 0; cb < CB; cb++) {
-                        sah[s][cb] = *reinterpret_cast<const frag*>(smem + aaddr[k][cb] + (wslab + dxi * 8192));
-                        sal[s][cb] = *reinterpret_cast<const frag*>(smem + aaddr[2 + k][cb] + (wslab + dxi * 8192));
-                    }
-#pragma unroll
-                    for (int pb = 0; pb < 2; pb++) {
-                        sbh[s][pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][k]);
-                        sbl[s][pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][2 + k]);
-                    }
-                };
-#pragma unroll
-                for (int i = 0; i < SA; i++) load_split(i, i % SR);
-                __builtin_amdgcn_sched_group_barrier(0x100, (2 * CB + 4) * SA, 0);
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    if (i + SA < 6) load_split(i + SA, (i + SA) % SR);
-                    const int s = i % SR;
-#pragma unroll
-                    for (int cb = 0; cb < CB; cb++)
-#pragma unroll
-                        for (int pb = 0; pb < 2; pb++) {
-                            Mfma<T>::mac(sal[s][cb], sbh[s][pb], acc[cb][pb]);
-                            Mfma<T>::mac(sah[s][cb], sbl[s][pb], acc[cb][pb]);
-                            Mfma<T>::mac(sah[s][cb], sbh[s][pb], acc[cb][pb]);
-                        }
-                    if (i + SA < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2 * CB + 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, CB * 6, 0);
-                }
-                continue;
-            }
             frag fa[RING][CB], fb[RING][2];
             auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[2]) {
                 const int dxi = i >> 2, ks = i & 3;
@@ -623,11 +554,8 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         if (HAS_RES && !RES_EARLY) {
 #pragma unroll
             for (int i = 0; i < EIT; i++) {
-                const size_t off = (wrow0 + i * RPT + prow) * orow + ocol;
-                if (SPLIT) {  // hi and lo values of the 8 channels
-                    reinterpret_cast<f32x4*>(resv[i])[0] = *reinterpret_cast<const f32x4*>(res + off);
-                    reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(res + off + 32);
-                } else if (sizeof(T) == 2) {
+                const size_t off = (wrow0 + i * RPT + prow) * (size_t)cout + cout0 + cg * 8;
+                if (sizeof(T) == 2) {
                     *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
                 } else {
                     reinterpret_cast<f32x4*>(resv[i])[0] = reinterpret_cast<const f32x4*>(res + off)[0];
@@ -644,12 +572,10 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             for (int pb = 0; pb < 2; pb++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
+                    const f32x4 bv = biasv[cb][g];
                     f32x4 v;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        if constexpr (SPLIT) v[i] = acc[cb][pb][g * 4 + i];
-                        else v[i] = acc[cb][pb][g * 4 + i] + biasv[cb][g][i];
-                    }
+                    for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
                     const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
                     *reinterpret_cast<f32x4*>(smem + stage_row(pb * 32 + r) + slot * 16) = v;
                 }
@@ -660,45 +586,12 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (px & 7)) << 4));
             const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (px & 7)) << 4));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if constexpr (SPLIT) {
-                // the accumulator carries the weights' power-of-two scale: times its inverse is exact
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = v[j] * ds8[j >> 2][j & 3] + bias8[j >> 2][j & 3];
-            }
-            const size_t off = (wrow0 + px) * orow + ocol;
+            const size_t off = (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
             if (HAS_RES) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    // SPLIT: hi + lo is exact in f32 (lo is at most half an ulp of hi: 22 significant bits)
-                    if constexpr (SPLIT) v[j] = v[j] + ((float)resv[i][j] + (float)resv[i][8 + j]);
-                    else v[j] = v[j] + (float)resv[i][j];
-                }
+                for (int j = 0; j < 8; j++) v[j] = v[j] + (float)resv[i][j];
             }
             const bool valid = pslot0 + px < S * S;
-            if constexpr (SPLIT) {
-                float y[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    y[j] = v[j] > 0.0f ? v[j] : 0.0f;
-                    if (!valid) y[j] = 0.0f;
-                }
-                if (flags & CONV_OUT_F32) {  // the tower's last layer: plain f32 rows for the head kernels
-                    float* of = reinterpret_cast<float*>(out) + (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
-                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y), reinterpret_cast<f32x4*>(of));
-                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y + 4), reinterpret_cast<f32x4*>(of) + 1);
-                } else {
-                    T hi[8], lo[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const float yc = y[j] < 65504.0f ? y[j] : 65504.0f;  // saturate instead of overflowing to infinity
-                        hi[j] = (T)yc;
-                        lo[j] = (T)(yc - (float)hi[j]);
-                    }
-                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(hi), reinterpret_cast<f32x4*>(out + off));
-                    __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(lo), reinterpret_cast<f32x4*>(out + off + 32));
-                }
-                continue;
-            }
             T ov[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -730,22 +623,399 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 int g_conv_cb = 0;  // 0: by grid size; 1 / 2: 32 / 64 couts per workgroup (CATTUS_CONV_CB, A/B runs and the equality test)
 void set_conv_cb(int v) { g_conv_cb = (v == 1 || v == 2) ? v : 0; }
 
+
+// ------------------------------------------------------------------------------------------
+// K1s: 3x3 conv of the split-precision tower (dtype f16x2)
+// ------------------------------------------------------------------------------------------
+//
+// Every activation and every weight is a PAIR of f16 values, x = hi + lo with hi = f16(x), lo = f16(x - hi) (22
+// significant bits), and a product is three MFMA terms, a_hi w_hi + a_lo w_hi + a_hi w_lo, accumulated in f32 (a_lo w_lo,
+// 2^-22 of the product, is dropped).  The f16 MFMA takes f16 subnormals as they are and sums its 16 products more
+// accurately than an f32 fmaf chain does (scripts/probes/mfma_f16_probe.hip -> profiles/r03_mfma_f16_probe.txt), so the
+// tower's error against a float64 run is that of an f32 runtime.
+//
+// HBM layout: pairs interleaved in groups of 32 channels -- 128 bytes of a row are [hi of 32 channels | lo of the same
+// 32], in `in` / `res` / `out` rows and in `w` rows alike -- so a chunk of the k walk carries 32 channels, as in the f32
+// kernel.  Weights are pre-scaled per output channel by a power of two (their lo halves stay normal f16 numbers); `bias`
+// is followed by the cout inverse scales, applied exactly in the epilogue.  The stem's planes are 0/1 (lo half zero).
+//
+// Same roles as conv3x3_mfma_v2_kernel (4 MFMA consumer waves with a 64 cout x 64 pixel tile each, 4 LDS-DMA loader
+// waves, a 3-slab weight ring, two activation chunk buffers, one barrier per (chunk, kernel row)), with two differences:
+//   * LDS rows have a pitch of 144 bytes (128 of data + 16 of padding) instead of an XOR swizzle: ds_read_b128 down 16
+//     consecutive rows is conflict-free either way, but with a pitch every fragment address is `row base + constant`, so
+//     tap, k-slice and hi / lo all fold into ds_read immediates; a step needs 6 vector adds of address arithmetic (the
+//     swizzled form: ~100 VALU instructions per step, 400 cycles of a 2,300-cycle step).  The loader waves build the
+//     padded image from dense global rows through their per-lane source addresses (the pad slot re-reads a data slot).
+//   * a consumer stage is (tap, 16 channels): the hi and lo fragments of 2 weight blocks and 2 pixel blocks (8
+//     ds_read_b128) feed 12 MFMAs, one stage (384 cycles of MFMA issue) of look-ahead.
+// flags & CONV_OUT_F32: the output is written as plain f32 [row][cout] (the last tower layer, for the f32 head kernels).
+constexpr int CONV_OUT_F32 = 1;
+constexpr int SP = 144;                                 // LDS row pitch
+constexpr int SP_TAP = 64 * SP;                         // the 64 cout rows of one tap
+constexpr int SP_SLAB = 3 * SP_TAP;                     // 27,648 B = 27 LDS-DMA pieces of 1 KiB
+constexpr int SP_ZERO = 256 * SP;                       // a buffer's zero row (off-board taps read it), behind its 256 rows
+constexpr int SP_ABUF = SP_ZERO + SP;                   // 37,008 B; the rows alone are 36 pieces
+constexpr int SP_LDS_ACT = 3 * SP_SLAB;
+constexpr int SP_LDS_TOTAL = SP_LDS_ACT + 2 * SP_ABUF;  // 156,960 B
+constexpr int SP_WPL = 7, SP_APL = 5;                   // pieces per loader wave: 28 >= 27 per slab, 20 >= 18 per half chunk
+
+template <bool HAS_RES, bool BIG, bool STEM, int CB>
+__global__ void __launch_bounds__(512, 2)
+    conv3x3_split_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ w, const float* __restrict__ bias,
+                         const _Float16* __restrict__ res, _Float16* __restrict__ out, int cin, int cout, int S, int flags,
+                         StemPlanes<STEM> sp) {
+    typedef _Float16 T;
+    typedef Mfma<T>::frag frag;
+    constexpr int KC = 32;        // channels (pairs) per 128-byte chunk
+    constexpr int CPW = 32 * CB;  // output channels of this workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const bool is_loader = wave >= 4;
+    STAMP_DECL;
+    STAMP(0);
+    STAMP_RT(5);
+
+    const int nblk = gridDim.x, ncb = cout / CPW;
+    int logical = blockIdx.x;
+    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int cout0 = (logical % ncb) * CPW;
+    const int row0 = (logical / ncb) * ROWS_PER_WG;
+
+    if (tid < 18) reinterpret_cast<f32x4*>(smem + SP_LDS_ACT + (tid / 9) * SP_ABUF + SP_ZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero rows are written before the first barrier
+
+    const int nch = cin / KC;
+    const int T_total = nch * 3;
+    const uint32_t row_bytes = (uint32_t)cin * 4;
+
+    if (is_loader) {
+        // ================================ loader waves ================================
+        // Piece `pid` fills image bytes [pid * 1024, +1024): lane l writes 16-byte slot pid * 64 + l of the image, i.e. slot
+        // c = that % 9 of image row that / 9; slot 8 is the padding (it re-reads slot 7).  A wave's surplus pieces repeat
+        // the image's last piece, so every wave issues the same count and the vmcnt arithmetic below stays uniform.
+        const int lw = wave - 4;
+        uint32_t off_w[SP_WPL], off_a[2][SP_APL];
+        int dst_w[SP_WPL], dst_a[2][SP_APL];
+#pragma unroll
+        for (int i = 0; i < SP_WPL; i++) {
+            const int pid = min(lw * SP_WPL + i, 26);
+            const int sidx = pid * 64 + lane, irow = sidx / 9, c = min(sidx - irow * 9, 7);
+            const int tap_i = irow >> 6, row = CB == 2 ? (irow & 63) : (irow & 31);  // CB = 1: rows 32..63 of a tap are not read
+            off_w[i] = ((uint32_t)(tap_i * cout + row)) * row_bytes + c * 16;
+            dst_w[i] = pid * 1024;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int i = 0; i < SP_APL; i++) {
+                const int id = g * 18 + min(lw * SP_APL + i, 17);
+                const int sidx = id * 64 + lane, irow = sidx / 9, c = min(sidx - irow * 9, 7);
+                off_a[g][i] = (uint32_t)irow * row_bytes + c * 16;
+                dst_a[g][i] = id * 1024;
+            }
+        const char* wbase0 = reinterpret_cast<const char*>(w) + (size_t)cout0 * row_bytes;
+        const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
+        auto issue_w = [&](int t) {  // weight slab of step t -> ring slot t % 3
+            const int ch = t / 3, g = t - ch * 3;
+            const char* src = wbase0 + (size_t)(g * 3) * cout * row_bytes + (size_t)ch * 128;
+            char* dst = smem + (t % 3) * SP_SLAB;
+#pragma unroll
+            for (int i = 0; i < SP_WPL; i++) glds16(src + off_w[i], dst + dst_w[i]);
+        };
+        auto issue_a = [&](int ch, int g) {  // half g of activation chunk ch -> buffer ch & 1
+            const char* src = abase0 + (size_t)ch * 128;
+            char* dst = smem + SP_LDS_ACT + (ch & 1) * SP_ABUF;
+#pragma unroll
+            for (int i = 0; i < SP_APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
+        };
+
+        if constexpr (STEM) {
+            // K0 fused: this thread expands pixel row (lw * 64 + lane) of the workgroup's 256 rows: channel c of the row is 1.0
+            // where plane c has the pixel's bit (hi half, slots 0..3); the lo half (slots 4..7) is zero
+            constexpr int MAXC = 32;
+            const int row = lw * 64 + lane;
+            const uint32_t grow = (uint32_t)(row0 + row), slots = BIG ? 128u : 64u;
+            const uint32_t board = grow / slots, px = grow % slots;
+            const bool live = board < sp.n && (int)px < S * S;
+            typedef const __attribute__((address_space(1))) uint64_t* gu64p;
+            const gu64p pl = (gu64p)(sp.planes + (size_t)(live ? board : 0) * sp.C * sp.w64 + (live ? (px >> 6) : 0));
+            uint64_t words[MAXC];
+#pragma unroll
+            for (int c = 0; c < MAXC; c++) words[c] = (live && (uint32_t)c < sp.C) ? pl[(size_t)c * sp.w64] : 0ull;
+            issue_w(0);
+            issue_w(1);
+            char* dstrow = smem + SP_LDS_ACT + row * SP;
+#pragma unroll
+            for (int sl = 0; sl < 8; sl++) {
+                T vals[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int c = sl * 8 + i;
+                    vals[i] = (c < MAXC && ((words[c < MAXC ? c : 0] >> (px & 63)) & 1ull)) ? (T)1.0f : (T)0.0f;
+                }
+                *reinterpret_cast<f32x4*>(dstrow + sl * 16) = *reinterpret_cast<f32x4*>(vals);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are written before the first barrier
+        } else {
+            issue_a(0, 0);
+            issue_a(0, 1);
+            issue_w(0);
+            issue_w(1);
+        }
+        int pending = SP_WPL;  // loads issued after the data of the upcoming step
+        for (int t = 0; t < T_total; t++) {
+            {
+#ifdef CATTUS_STAMPS
+                const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+                if (pending == SP_WPL + SP_APL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_WPL + SP_APL) : "memory");
+                else if (pending == SP_WPL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_WPL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+                asm volatile("s_barrier" ::: "memory");
+                st_[4] += t1_ - t0_;
+                st_[7] += __builtin_amdgcn_s_memtime() - t1_;
+#else
+                if (pending == SP_WPL + SP_APL) wait_vm_barrier<SP_WPL + SP_APL>();
+                else if (pending == SP_WPL) wait_vm_barrier<SP_WPL>();
+                else wait_vm_barrier<0>();
+#endif
+            }
+            if (t == 0) STAMP(1);
+            pending = 0;
+            const int ch = t / 3, g = t - ch * 3;
+            if (t + 2 < T_total) {
+                issue_w(t + 2);
+                pending += SP_WPL;
+            }
+            if (g < 2 && ch + 1 < nch) {
+                issue_a(ch + 1, g);
+                pending += SP_APL;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(2);
+        STAMP(3);
+        STAMP_RT(6);
+        STAMP_FLUSH(wave);
+        return;
+    }
+
+    // ================================ consumer waves ================================
+    const int r = lane & 31, h = lane >> 5;
+    const int pslot0 = BIG ? (wave & 1) * 64 : 0;
+    const int board_row = BIG ? (wave >> 1) * 128 : wave * 64;  // first LDS row of this wave's board
+    // Byte offset, inside an activation buffer, of the row each tap reads for this lane's two pixels (the buffer's zero
+    // row for a tap off the board), plus the lane half's 16 bytes: loop-invariant; a step adds the buffer's base.
+    int rowa[9][2];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) {
+        const int p = pslot0 + pb * 32 + r;
+        const int ph = p / S, pw = p - ph * S;
+        const bool pvalid = p < S * S;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; t9++) {
+            const int hh = ph + t9 / 3 - 1, ww = pw + t9 % 3 - 1;
+            const bool ok = pvalid && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
+            rowa[t9][pb] = (ok ? (board_row + hh * S + ww) * SP : SP_ZERO) + h * 16;
+        }
+    }
+    int aaddr[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) aaddr[cb] = (cb * 32 + r) * SP + h * 16;
+
+    f32x16 acc[CB][2];
+#pragma unroll
+    for (int i = 0; i < CB; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    // epilogue store layout: a pixel row of the tile is CPW couts = LPR lanes x 8 couts; 64 / LPR rows per trip.  The bias
+    // and the inverse weight scale of the 8 couts the lane owns after the transpose, and the skip rows, are requested now.
+    constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = 64 / RPT;
+    const int prow = lane / LPR, cg = lane % LPR;
+    f32x4 bias8[2], ds8[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        bias8[q] = *reinterpret_cast<const f32x4*>(bias + cout0 + cg * 8 + q * 4);
+        ds8[q] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cg * 8 + q * 4);
+    }
+    const size_t orow = (size_t)cout * 2;  // elements of T per row of `res` / `out`
+    const int ocol = ((cout0 + cg * 8) >> 5) * 64 + ((cout0 + cg * 8) & 31);  // hi values of the lane's 8 couts; lo 32 further
+    // The skip rows (64 KiB per workgroup) are requested behind the first barrier, not here: the prologue is a burst of
+    // ~90 KiB per CU that every workgroup of the chip issues at once, and these have the whole loop to arrive (measured
+    // against requesting them here: no difference, 1.770 vs 1.773 ms per batch; profiles/r03_experiments.txt).
+    T resv[EIT][16];
+    auto request_skip_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < EIT; i++) {
+            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * orow + ocol;
+            reinterpret_cast<f32x4*>(resv[i])[0] = *reinterpret_cast<const f32x4*>(res + off);
+            reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(res + off + 32);
+        }
+    };
+
+    int opaque = 0;
+    for (int ch = 0; ch < nch; ch++) {
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            // all fragment reads of the previous step have returned before the loaders may reuse its slab
+            {
+                STAMP_ACC_BEGIN;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                STAMP_ACC_END(4);
+            }
+            if (ch == 0 && g == 0) STAMP(1);
+            if (HAS_RES && ch == 0 && g == 0) request_skip_rows();
+            asm volatile("" : "+v"(opaque));  // keeps the six sums below inside the loop (both parities hoisted: 12 more VGPRs)
+            const int bufbase = SP_LDS_ACT + (ch & 1) * SP_ABUF + opaque;
+            const int wslab = g * SP_SLAB;  // ring slot of step ch * 3 + g is g
+            int ba[3][2];
+#pragma unroll
+            for (int dxi = 0; dxi < 3; dxi++)
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) ba[dxi][pb] = rowa[g * 3 + dxi][pb] + bufbase;
+            // stage i = (tap dxi, 16 channels k): slots k and 2 + k of the rows hold the hi and the lo halves
+            frag sah[2][CB], sal[2][CB], sbh[2][2], sbl[2][2];
+            auto load_stage = [&](int i, int s) {
+                const int dxi = i >> 1, k = i & 1;
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) {
+                    sah[s][cb] = *reinterpret_cast<const frag*>(smem + aaddr[cb] + (wslab + dxi * SP_TAP + k * 32));
+                    sal[s][cb] = *reinterpret_cast<const frag*>(smem + aaddr[cb] + (wslab + dxi * SP_TAP + k * 32 + 64));
+                }
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) {
+                    sbh[s][pb] = *reinterpret_cast<const frag*>(smem + ba[dxi][pb] + k * 32);
+                    sbl[s][pb] = *reinterpret_cast<const frag*>(smem + ba[dxi][pb] + k * 32 + 64);
+                }
+            };
+            load_stage(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * CB + 4, 0);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                if (i + 1 < 6) load_stage(i + 1, (i + 1) & 1);
+                const int s = i & 1;
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++) {
+                        Mfma<T>::mac(sal[s][cb], sbh[s][pb], acc[cb][pb]);
+                        Mfma<T>::mac(sah[s][cb], sbl[s][pb], acc[cb][pb]);
+                        Mfma<T>::mac(sah[s][cb], sbh[s][pb], acc[cb][pb]);
+                    }
+                // pin the issue order: this stage's look-ahead reads, then its MFMAs
+                if (i + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2 * CB + 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CB * 6, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: transpose through the wave's own (idle) activation rows as in conv3x3_mfma_v2_kernel, then per lane 8
+    // consecutive couts of one pixel: * inverse scale + bias, + skip, ReLU, split into (hi, lo), two 16-byte stores ----
+    STAMP(2);
+    if (BIG) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the board's other wave may still read these rows
+    {
+        const size_t wrow0 = (size_t)row0 + wave * 64;
+        const int tile0 = SP_LDS_ACT + wave * 64 * SP;  // the wave's 64 rows of buffer 0 (9,216 B); the same rows of buffer 1 behind
+        // staged tile: CB = 2: f32 [px][64 couts] = 256-byte rows, px 0..31 in buffer 0, px 32..63 in buffer 1;
+        //              CB = 1: f32 [px][32 couts] = 128-byte rows, all 64 in buffer 0
+        auto stage_row = [&](int px) { return CB == 2 ? tile0 + (px >> 5) * SP_ABUF + (px & 31) * 256 : tile0 + px * 128; };
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i];
+                    const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
+                    *reinterpret_cast<f32x4*>(smem + stage_row(pb * 32 + r) + slot * 16) = v;
+                }
+#pragma unroll
+        for (int i = 0; i < EIT; i++) {
+            const int px = i * RPT + prow;
+            const char* rowp = smem + stage_row(px);
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (px & 7)) << 4));
+            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (px & 7)) << 4));
+            float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            // the accumulator carries the weights' power-of-two scale: times its inverse is exact
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = v[j] * ds8[j >> 2][j & 3] + bias8[j >> 2][j & 3];
+            if (HAS_RES) {
+                // hi + lo is exact in f32 (lo is at most half an ulp of hi: 22 significant bits)
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = v[j] + ((float)resv[i][j] + (float)resv[i][8 + j]);
+            }
+            const bool valid = pslot0 + px < S * S;
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                y[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                if (!valid) y[j] = 0.0f;
+            }
+            if (flags & CONV_OUT_F32) {  // the tower's last layer: plain f32 rows for the head kernels
+                float* of = reinterpret_cast<float*>(out) + (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y), reinterpret_cast<f32x4*>(of));
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y + 4), reinterpret_cast<f32x4*>(of) + 1);
+            } else {
+                const size_t off = (wrow0 + px) * orow + ocol;
+                T hi[8], lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float yc = y[j] < 65504.0f ? y[j] : 65504.0f;  // saturate instead of overflowing to infinity
+                    hi[j] = (T)yc;
+                    lo[j] = (T)(yc - (float)hi[j]);
+                }
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(hi), reinterpret_cast<f32x4*>(out + off));
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(lo), reinterpret_cast<f32x4*>(out + off + 32));
+            }
+        }
+    }
+    STAMP(3);
+    STAMP_RT(6);
+    STAMP_FLUSH(wave);
+}
+
 // Every conv variant that exists, with its opt-in for > 64 KiB of dynamic LDS (a per-device function attribute).
 // Called once per device from cattus_hip_create (under its lock), so that no launch ever races the attribute call.
-template <typename T, bool SPLIT>
+template <typename T>
 static hipError_t conv_attrs_for() {
     hipError_t err = hipSuccess;
     auto set = [&](const void* fn) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_TOTAL);
         if (e != hipSuccess && err == hipSuccess) err = e;
     };
-#define CATTUS_ATTR_CB(CBV)                                                                                  \
-    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, false, false, CBV, SPLIT>));         \
-    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, true, false, false, CBV, SPLIT>));          \
-    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, true, false, CBV, SPLIT>));          \
-    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, true, true, false, CBV, SPLIT>));           \
-    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, false, true, CBV, SPLIT>));          \
-    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, true, true, CBV, SPLIT>));
+#define CATTUS_ATTR_CB(CBV)                                                                           \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, false, false, CBV>));         \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, true, false, false, CBV>));          \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, true, false, CBV>));          \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, true, true, false, CBV>));           \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, false, true, CBV>));          \
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, true, true, CBV>));
+    CATTUS_ATTR_CB(1)
+    CATTUS_ATTR_CB(2)
+#undef CATTUS_ATTR_CB
+    return err;
+}
+static hipError_t split_attrs() {
+    hipError_t err = hipSuccess;
+    auto set = [&](const void* fn) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_TOTAL);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+    };
+#define CATTUS_ATTR_CB(CBV)                                                                  \
+    set(reinterpret_cast<const void*>(&conv3x3_split_kernel<false, false, false, CBV>));     \
+    set(reinterpret_cast<const void*>(&conv3x3_split_kernel<true, false, false, CBV>));      \
+    set(reinterpret_cast<const void*>(&conv3x3_split_kernel<false, true, false, CBV>));      \
+    set(reinterpret_cast<const void*>(&conv3x3_split_kernel<true, true, false, CBV>));       \
+    set(reinterpret_cast<const void*>(&conv3x3_split_kernel<false, false, true, CBV>));      \
+    set(reinterpret_cast<const void*>(&conv3x3_split_kernel<false, true, true, CBV>));
     CATTUS_ATTR_CB(1)
     CATTUS_ATTR_CB(2)
 #undef CATTUS_ATTR_CB
@@ -761,34 +1031,58 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
     int cb = full_grid <= 128 ? 1 : 2;
     if (g_conv_cb) cb = g_conv_cb;
     const dim3 grid(full_grid * (cb == 1 ? 2 : 1));
-#define CATTUS_LAUNCH_CONV2(T, R, BIG, CBV, SP)                                                           \
-    hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV, SP>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                          (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, flags, StemPlanes<false>{})
-#define CATTUS_LAUNCH_STEM(T, BIG, CBV, SP)                                                               \
-    hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV, SP>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                          (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, flags, \
+    if (act == Act::F16S) {
+        typedef _Float16 H;
+#define CATTUS_LAUNCH_SPLIT(R, BIG, STEMV, CBV, SPV)                                                                          \
+    hipExtLaunchKernelGGL((conv3x3_split_kernel<R, BIG, STEMV, CBV>), grid, dim3(512), SP_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                          (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S, flags, SPV)
+#define CATTUS_LAUNCH_SPLIT_CB(CBV)                                                                       \
+    do {                                                                                                  \
+        if (stem) {                                                                                       \
+            const StemPlanes<true> spv{stem->planes, stem->n, stem->C, stem->w64};                        \
+            if (slots == 128) CATTUS_LAUNCH_SPLIT(false, true, true, CBV, spv);                           \
+            else CATTUS_LAUNCH_SPLIT(false, false, true, CBV, spv);                                       \
+        } else if (slots == 128) {                                                                        \
+            if (res) CATTUS_LAUNCH_SPLIT(true, true, false, CBV, StemPlanes<false>{});                    \
+            else CATTUS_LAUNCH_SPLIT(false, true, false, CBV, StemPlanes<false>{});                       \
+        } else {                                                                                          \
+            if (res) CATTUS_LAUNCH_SPLIT(true, false, false, CBV, StemPlanes<false>{});                   \
+            else CATTUS_LAUNCH_SPLIT(false, false, false, CBV, StemPlanes<false>{});                      \
+        }                                                                                                 \
+    } while (0)
+        if (cb == 1) CATTUS_LAUNCH_SPLIT_CB(1);
+        else CATTUS_LAUNCH_SPLIT_CB(2);
+#undef CATTUS_LAUNCH_SPLIT_CB
+#undef CATTUS_LAUNCH_SPLIT
+        return;
+    }
+#define CATTUS_LAUNCH_CONV2(T, R, BIG, CBV)                                                               \
+    hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                          (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{})
+#define CATTUS_LAUNCH_STEM(T, BIG, CBV)                                                                   \
+    hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                          (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
                           StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64})
-#define CATTUS_LAUNCH_CONV2_CB(T, CBV, SP)                            \
-    do {                                                              \
-        if (stem) {                                                   \
-            if (slots == 128) CATTUS_LAUNCH_STEM(T, true, CBV, SP);   \
-            else CATTUS_LAUNCH_STEM(T, false, CBV, SP);               \
-        } else if (slots == 128) {                                    \
-            if (res) CATTUS_LAUNCH_CONV2(T, true, true, CBV, SP);     \
-            else CATTUS_LAUNCH_CONV2(T, false, true, CBV, SP);        \
-        } else {                                                      \
-            if (res) CATTUS_LAUNCH_CONV2(T, true, false, CBV, SP);    \
-            else CATTUS_LAUNCH_CONV2(T, false, false, CBV, SP);       \
-        }                                                             \
+#define CATTUS_LAUNCH_CONV2_CB(T, CBV)                            \
+    do {                                                          \
+        if (stem) {                                               \
+            if (slots == 128) CATTUS_LAUNCH_STEM(T, true, CBV);   \
+            else CATTUS_LAUNCH_STEM(T, false, CBV);               \
+        } else if (slots == 128) {                                \
+            if (res) CATTUS_LAUNCH_CONV2(T, true, true, CBV);     \
+            else CATTUS_LAUNCH_CONV2(T, false, true, CBV);        \
+        } else {                                                  \
+            if (res) CATTUS_LAUNCH_CONV2(T, true, false, CBV);    \
+            else CATTUS_LAUNCH_CONV2(T, false, false, CBV);       \
+        }                                                         \
     } while (0)
-#define CATTUS_LAUNCH_CONV2_T(T, SP)                  \
-    do {                                              \
-        if (cb == 1) CATTUS_LAUNCH_CONV2_CB(T, 1, SP); \
-        else CATTUS_LAUNCH_CONV2_CB(T, 2, SP);        \
+#define CATTUS_LAUNCH_CONV2_T(T)                  \
+    do {                                          \
+        if (cb == 1) CATTUS_LAUNCH_CONV2_CB(T, 1); \
+        else CATTUS_LAUNCH_CONV2_CB(T, 2);        \
     } while (0)
-    if (act == Act::BF16) CATTUS_LAUNCH_CONV2_T(__bf16, false);
-    else if (act == Act::F16S) CATTUS_LAUNCH_CONV2_T(_Float16, true);
-    else CATTUS_LAUNCH_CONV2_T(float, false);
+    if (act == Act::BF16) CATTUS_LAUNCH_CONV2_T(__bf16);
+    else CATTUS_LAUNCH_CONV2_T(float);
 #undef CATTUS_LAUNCH_CONV2_T
 #undef CATTUS_LAUNCH_CONV2_CB
 #undef CATTUS_LAUNCH_STEM
@@ -1265,10 +1559,10 @@ void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, bool layer_s
 // device, before anything is launched on that device: cattus_hip_create calls this under a lock, so two evaluation
 // threads can never meet a variant whose attribute call is still on its way.
 hipError_t prepare_device() {
-    hipError_t err = conv_attrs_for<__bf16, false>();
-    hipError_t e2 = conv_attrs_for<float, false>();
+    hipError_t err = conv_attrs_for<__bf16>();
+    hipError_t e2 = conv_attrs_for<float>();
     if (err == hipSuccess) err = e2;
-    e2 = conv_attrs_for<_Float16, true>();
+    e2 = split_attrs();
     if (err == hipSuccess) err = e2;
     auto set = [&](const void* fn, int bytes) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
