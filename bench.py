@@ -512,7 +512,8 @@ def main():
             assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
         ev.close()
         return dict(elapsed=elapsed, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2,
-                    kernel="tower64_lds_kernel" if launches == 1 else "conv3x3_mfma_v2_kernel", settle_steps=settle_steps, settle_ms=settle_ms)
+                    kernel="tower64_lds_kernel" if launches == 1 else "conv3x3_split_kernel" if dtype == "f16x2" else "conv3x3_mfma_v2_kernel",
+                    settle_steps=settle_steps, settle_ms=settle_ms)
 
     def roofline(dtype, r):
         """Dominant kernel = the tower conv launch.  `achieved` counts ALGORITHMIC flops (2 x multiply-adds of the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""End-to-end self-play throughput on one GPU: chess 20x256 bf16, batch 256.
+"""End-to-end self-play throughput on one GPU: chess 20x256, batch 256.
 
-    python scripts/e2e_selfplay.py THREADS SLOTS SIMS GAMES [diverse] [devsoftmax] [serial] [lif=K] [batch=B] [plies=P]
+    python scripts/e2e_selfplay.py THREADS SLOTS SIMS GAMES [diverse] [devsoftmax] [serial] [lif=K] [batch=B] [plies=P] [dtype=f16x2|bf16|f32]
 
 ``diverse`` uses the reference's self-play settings (temperature 1.0 for the first 30 moves,
 Dirichlet noise 0.03/0.25: training/config/chess_dev.yaml:52-68,83-88) so that games differ and the
@@ -9,6 +9,7 @@ evaluation cache sees a realistic hit rate; without it every game is the same de
 """
 import json
 import sys
+import threading
 import time
 
 sys.path.insert(0, ".")
@@ -23,17 +24,28 @@ lif = max([int(a[4:]) for a in sys.argv[5:] if a.startswith("lif=")] or [1])  # 
 batch = max([int(a[6:]) for a in sys.argv[5:] if a.startswith("batch=")] or [256])  # leaves per batch (search side)
 plies = max([int(a[6:]) for a in sys.argv[5:] if a.startswith("plies=")] or [0])  # adjudicate after this many plies (0: play out)
 devsoftmax = "devsoftmax" in sys.argv[5:]  # legal-move softmax on the GPU (cattus_hip_eval_legal)
+dtype = ([a[6:] for a in sys.argv[5:] if a.startswith("dtype=")] or ["f16x2"])[-1]
 d = NetDesc(**CHESS, blocks=20, filters=256, vhc=8, phc=8)
 blob = seeded_blob(d, 2)
-with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="bf16") as ev:
+with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype) as ev:
+    stop = threading.Event()
+
+    def heartbeat():  # a long run keeps saying it is alive (evaluator statistics once a minute)
+        t0 = time.time()
+        while not stop.wait(60):
+            st = ev.stats()
+            print(f"[{time.time() - t0:5.0f} s] {st['positions']} leaves in {st['batches']} batches", file=sys.stderr, flush=True)
+
+    threading.Thread(target=heartbeat, daemon=True).start()
     kw = dict(temperature_policy=[(30, 1.0), (9999, 0.0)], prior_noise_alpha=0.03, prior_noise_epsilon=0.25) if diverse else {}
     cfg = sp.make_config(sim_num=sims, batch_size=batch, max_game_plies=plies, threads=threads, concurrent_games=slots, cache_size=1000000, eval_threads=eval_threads, leaves_in_flight=lif, **kw)
     t = time.time()
     res = sp.run_self_play("chess", cfg, sp.Net.hip(ev, device_softmax=devsoftmax), None, games, keep_records=False)
     dt = time.time() - t
     st = ev.stats()
+    stop.set()
 print(json.dumps(dict(
-    threads=threads, slots=slots, sims=sims, games=games, diverse=diverse, device_softmax=devsoftmax, eval_threads=eval_threads, leaves_in_flight=lif, batch=batch, max_game_plies=plies, seconds=round(dt, 3),
+    dtype=dtype, threads=threads, slots=slots, sims=sims, games=games, diverse=diverse, device_softmax=devsoftmax, eval_threads=eval_threads, leaves_in_flight=lif, batch=batch, max_game_plies=plies, seconds=round(dt, 3),
     node_evals=res["node_evals"], evals_per_s=round(res["node_evals"] / dt),
     steady_evals_per_s=round(res["steady_node_evals"] / res["steady_seconds"]), steady_seconds=round(res["steady_seconds"], 2), batches=res["activation_count"],
     batch_fill=round(res["node_evals"] / max(1, res["activation_count"]), 1), positions=res["positions"],

@@ -28,19 +28,41 @@ out = {
     "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
     "by_dtype": {},
 }
+def base_name(k: str) -> str:
+    """Kernel name without namespace and template arguments, from a demangled or an Itanium-mangled name."""
+    import re
+
+    m = re.match(r"_ZN6cattus(\d+)", k)
+    if m:
+        n = int(m.group(1))
+        return k[m.end() : m.end() + n]
+    return k.replace("void ", "").replace("cattus::", "").split("<")[0].split("(")[0].strip()
+
+
+TOWER = {"f16x2": "conv3x3_split_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
 for dtype in ("f16x2", "bf16", "f32"):
     f = tag / f"pmc_summary_{dtype}.json"
     if not f.exists():
         continue
     summ = json.loads(f.read_text())
-    entry = {}
+    acc = {}  # base name -> [sum of traffic x launches, launches, variants]
     for k, v in summ.items():
         if "traffic_bytes_per_launch" not in v:
             continue
-        name = k.replace("cattus::", "")
-        entry[name] = {"traffic_bytes_per_launch": v["traffic_bytes_per_launch"]}
-        if name == "conv3x3_mfma_v2_kernel":
+        n = v["FETCH_SIZE"]["launches"]
+        a = acc.setdefault(base_name(k), [0.0, 0, {}])
+        a[0] += v["traffic_bytes_per_launch"] * n
+        a[1] += n
+        a[2][k[:110]] = {"traffic_bytes_per_launch": v["traffic_bytes_per_launch"], "launches": n}
+    entry = {}
+    for name, (tot, n, variants) in acc.items():
+        entry[name] = {"traffic_bytes_per_launch": int(tot / n), "launches": n}
+        if len(variants) > 1:
+            entry[name]["by_variant"] = variants
+        if name == TOWER[dtype]:
             entry[name]["algorithmic_bytes_per_launch"] = int(ALG[dtype])
+            entry[name]["note"] = ("average over the 41 launches of a step (stem, 20 convs without and 20 with the skip rows); the excess over the "
+                                   "algorithmic bytes is the layer's weight set fetched once per XCD L2 (8 of them) instead of once")
     out["by_dtype"][dtype] = entry
     if "planes_to_tensor_nchw64_kernel" in entry:
         out["by_dtype"].setdefault("any", {})["planes_to_tensor_nchw64_kernel"] = dict(entry["planes_to_tensor_nchw64_kernel"], algorithmic_bytes_per_launch=262144 * 4752)
