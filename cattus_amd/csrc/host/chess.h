@@ -10,7 +10,7 @@
 //   * legal-move iteration order (it fixes child insertion order in the search): piece kinds in the
 //     order pawn, knight, bishop, rook, queen, king; sources ascending; destinations ascending;
 //     promotions queen, knight, rook, bishop.  [unpinned]
-// What IS pinned by the reference's own tests is restated in tests/test_chess_rules.py
+// What IS pinned by the reference's own tests is restated in tests/test_host_rules.py
 // (chess/core.rs:617-729): a mating line, the custom fifty-move counter, flip involution and
 // flip/legal-move commutation; plus the public perft node counts.
 #pragma once

@@ -172,3 +172,43 @@ def test_full_loop_smoke_every_game(game, size):
         e = records.parse_record(game, rec.tobytes())
         legal = e.probs >= 0
         assert legal.sum() >= 1 and abs(e.probs[legal].sum() - 1) < 1e-4
+
+
+def test_config4_shape_64_games_with_rccl_pooling():
+    """BASELINE config 4's per-GPU shape as a test: chess 20x256, 64 concurrent games on this GPU (sequential search: at
+    most 64 leaves per batch), the records all-gathered and the counters all-reduced through torch.distributed's `nccl`
+    backend (= RCCL) -- with the one rank this box has; the 2-rank path is tests/test_dist.py on gloo."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from cattus_amd import dist as cdist
+
+    d = NetDesc(**CHESS, blocks=20, filters=256, vhc=8, phc=8)
+    blob = seeded_blob(d, 2)
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29300 + os.getpid() % 500}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        first, stride, local_games = cdist.shard_games(64, dist.get_rank(), dist.get_world_size())
+        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
+            cfg = sp.make_config(sim_num=100, batch_size=256, threads=8, concurrent_games=64, cache_size=1000000, first_game=first,
+                                 game_stride=stride, seed=1, max_game_plies=3, temperature_policy=[(30, 1.0), (9999, 0.0)],
+                                 prior_noise_alpha=0.03, prior_noise_epsilon=0.25)
+            res = sp.run_self_play("chess", cfg, sp.Net.hip(ev), None, local_games)
+            st = ev.stats()
+        dev = torch.device("cuda", 0)
+        recs, meta = cdist.pool_records(res["record_bytes"], res["record_meta"], device=dev)
+        tot = cdist.reduce_counters(res, device=dev)
+        assert dist.get_backend() == "nccl"
+        assert len(recs) == tot["positions"] == 64 * 3 and recs.shape[1] == records.record_nbytes("chess")
+        assert tot["player1_wins"] + tot["player2_wins"] + tot["draws"] == 64
+        assert sorted(set(meta[:, 0].tolist())) == list(range(64))  # every global game index once per ply
+        assert st["positions"] / st["batches"] <= 64.0  # one leaf per tree in flight: a batch holds at most 64 leaves
+        e = records.parse_record("chess", recs[0].tobytes())
+        assert abs(e.probs[e.probs >= 0].sum() - 1) < 1e-4
+    finally:
+        if started:
+            dist.destroy_process_group()
