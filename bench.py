@@ -584,7 +584,7 @@ def main():
         agreement.update(games=games, sims_per_move=800, searched_plies_per_game=args.agreement_plies, seconds=time.perf_counter() - t0,
                          note="f32 plays; each tower searches the same positions (teacher-forced, trees carried over); greedy move choice, noise "
                               "off. tests/test_search_parity_gpu.py runs 16 plies per game and bounds these numbers; larger samples: "
-                              "profiles/r03_search_agreement_*.json")
+                              "profiles/r03_search_agreement.json")
 
     # ---- end-to-end self-play legs (all ranks; each plays its own shard of the games)
     sp_out = sp_full = sp_c4 = None

@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None)
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--filters", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "bf16", "f32"])
     ap.add_argument("--games-num", type=int, default=128)
     ap.add_argument("--sim-num", type=int, default=800)
     ap.add_argument("--batch-size", type=int, default=256)
@@ -50,7 +50,13 @@ def main():
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     backend = args.backend or ("nccl" if args.net == "hip" else "gloo")
+    # a disjoint CPU share per rank, on its GPU's NUMA node where sysfs tells (before any worker thread exists)
+    from cattus_amd import affinity
+
+    share = affinity.pin_rank(local_rank, local_world, affinity.torch_pci_bus_ids(local_world) if backend == "nccl" and local_world > 1 else None)
+    args.threads = max(1, min(args.threads, len(share) - 3)) if local_world > 1 else args.threads
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -93,6 +99,7 @@ def main():
             "node_evals": tot["node_evals"], "seconds_play": play_s, "seconds_total": total_s,
             "node_evals_per_sec": tot["node_evals"] / play_s, "games_per_hour": args.games_num * 3600 / total_s,
             "pool_seconds": total_s - play_s,
+            "ranks": dist.get_world_size(), "collective_backend": dist.get_backend(), "threads_per_rank": args.threads,
         }
         assert len(recs) == tot["positions"]
         print(json.dumps(out), flush=True)

@@ -36,7 +36,7 @@ BF16_MOVE_AGREEMENT_MIN = 0.90
 BF16_VISIT_L1_MEAN_MAX = 0.0075
 BF16_VISIT_L1_MAX = 0.09
 # f16x2 (per-leaf error ~1e-6): a near-tie in a PUCT comparison can still fall the other way; over these 256 searches
-# at most 2 chosen moves may differ (>= 99.2 %), see profiles/r03_search_agreement_f16x2.json for 2,048 and 3,888 searches
+# at most 2 chosen moves may differ (>= 99.2 %), see profiles/r03_search_agreement.json for 2,048 and 3,888 searches
 F16X2_MOVE_AGREEMENT_MIN = 0.992
 F16X2_VISIT_L1_MEAN_MAX = 4e-4
 
