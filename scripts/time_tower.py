@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Event-stamped tower launch duration of bench workloads: python scripts/time_tower.py [--warm REPS] WORKLOAD..."""
+"""Event-stamped tower launch duration of bench workloads: python scripts/time_tower.py [--batch N] [--warm REPS] WORKLOAD[:DTYPE]...
+(DTYPE f16x2 by default)"""
 import sys
 
 sys.path.insert(0, ".")
@@ -16,7 +17,7 @@ if args and args[0] == "--warm":
 for wl in args:
     d, blob, planes = bench.make_workload(wl.split(":")[0])
     n = batch or len(planes)
-    dtype = "f32" if wl.endswith(":f32") else "bf16"
+    dtype = wl.split(":")[1] if ":" in wl else "f16x2"
     ev = HipEvaluator(blob, batch_size=max(n, len(planes)), plane_words=planes.shape[2], dtype=dtype)
     ev.time_tower(n, warm)
     us, launches = ev.time_tower(n, 200 if dtype == "bf16" else 20)
