@@ -2,7 +2,9 @@
 //
 //   K0  planes_to_tensor_nchw[64] / pack_planes_nhwc    bitboards -> tensors (HBM-bound); inside the forward pass the
 //                                                       planes are expanded straight into LDS by K1 / K1r instead
-//   K1  conv3x3_mfma_v2<T, HAS_RES, BIG, STEM>          3x3 conv + folded BN (+skip) + ReLU, one launch per layer (MFMA-bound)
+//   K1  conv3x3_mfma_v2<T, HAS_RES, BIG, STEM>          3x3 conv + folded BN (+skip) + ReLU, one launch per layer (MFMA-bound), bf16 / f32
+//   K1s conv3x3_split<HAS_RES, BIG, STEM, CB>           the same layer of the split-precision tower (dtype f16x2, the default):
+//                                                       operands as pairs of f16 values, three f16 MFMA terms per product
 //   K1r tower64_lds<CH, BIG>                            whole tower of a <= 64-filter bf16 network in one launch, activations in LDS
 //   K1g conv3x3_generic                                 same arithmetic, any shape, SIMT f32 (checker; wide heads)
 //   K3  head_conv, K4 + K5 head_fc_pair                 1x1 head convs; value FC1 + FC2 + tanh and policy FC (MFMA)
@@ -12,7 +14,8 @@
 // (reference: training/cattus_train/net_utils.py:4-89) on the tensor planes_to_tensor builds
 // (reference: engine/src/net/mod.rs:121-156).  In f32 mode every output is an in-order fmaf
 // chain (v_mfma_f32_32x32x2_f32 chains k in issue order), in the order documented in DESIGN.md,
-// so results are bit-identical across batch sizes, batch compositions and to the CPU oracle.
+// so results are bit-identical across batch sizes, batch compositions and to the CPU oracle.  The split-precision and
+// bf16 towers are bit-reproducible and batch-independent too, within the error bounds stated in DESIGN.md section 4.
 #include "kernels.h"
 
 #include <hip/hip_ext.h>
