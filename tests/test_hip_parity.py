@@ -110,6 +110,37 @@ def test_f16x2_within_the_reference_tolerance(name):
     assert np.abs(got_v - z["value_f64"]).max() <= F16X2_VALUE_ATOL_VS_F64, np.abs(got_v - z["value_f64"]).max()
 
 
+@pytest.mark.parametrize("game,desc,words,n", [
+    ("hex7", dict(**hex_game(7), blocks=6, filters=64, vhc=16, phc=16), 2, 128),    # BASELINE config 2
+    ("hex7", dict(**hex_game(7), blocks=3, filters=64, vhc=16, phc=16), 2, 1100),   # many workgroups, ragged batch
+    ("chess", dict(**CHESS, blocks=7, filters=16, vhc=8, phc=8), 1, 300),           # the reference's chess net: padded channels
+    ("hex11", dict(**hex_game(11), blocks=2, filters=8, vhc=4, phc=4), 2, 37),      # 128-slot boards
+    ("hex9", dict(**hex_game(9), blocks=2, filters=40, vhc=16, phc=16), 2, 600),    # 128-slot boards, 600 of them
+    ("hex5", dict(**hex_game(5), blocks=4, filters=96, vhc=8, phc=8), 2, 77),       # 96 filters: padded to 128, two cout slabs
+    ("ttt", dict(planes=3, board=3, moves=9, blocks=5, filters=8, vhc=8, phc=8), 1, 5),
+])
+def test_f16x2_tracks_the_f32_tower_on_every_shape(game, desc, words, n):
+    """The split tower on the shapes the other towers are tested on -- 64- and 128-slot boards, padded channels, several
+    output-channel slabs, ragged batches, both workgroup tiles: every leaf inside the reference's cross-runtime bar of the
+    bit-exact f32 tower's result, and independent of the batch it came in."""
+    d = NetDesc(**desc)
+    blob = seeded_blob(d, 17)
+    rng = np.random.default_rng(5)
+    hw = d.board * d.board
+    planes = np.zeros((n, d.planes, words), dtype=np.uint64)
+    bits = rng.integers(0, 2, size=(n, d.planes, hw), dtype=np.uint64)
+    for i in range(hw):
+        planes[:, :, i >> 6] |= bits[:, :, i] << np.uint64(i & 63)
+    with HipEvaluator(blob, batch_size=n, plane_words=words, dtype="f32") as ev:
+        want_p, want_v = ev.eval(planes)
+    with HipEvaluator(blob, batch_size=n + 3, plane_words=words, dtype="f16x2") as ev:
+        got_p, got_v = ev.eval(planes)
+        k = max(1, n // 3)
+        sub_p, sub_v = ev.eval(planes[k : 2 * k + 1])
+    assert outputs_equal_ref_tol(got_p, got_v, want_p, want_v), (np.abs(got_p - want_p).max(), np.abs(got_v - want_v).max())
+    assert (sub_p == got_p[k : 2 * k + 1]).all() and (sub_v == got_v[k : 2 * k + 1]).all()
+
+
 def test_f16x2_range_large_batchnorm_scales():
     """f16 holds 65504 at most.  Weights are safe whatever their size (each output channel is pre-scaled by a power of two
     and un-scaled exactly in the epilogue); activations are stored as they are.  A stem BatchNorm weight of 200 puts
