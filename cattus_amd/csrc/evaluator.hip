@@ -227,6 +227,10 @@ struct cattus_eval {
     cattus_net_desc d{};
     cattus_eval_config cfg{};
     bool tuned = false;  // MFMA NHWC tower vs generic NCHW f32 tower
+    // SimpleTwoHeadedModel (training/cattus_train/net_utils.py:92-121; blob with filters == 0): planes -> f32 tensor -> two dense
+    // layers + ReLU -> a dense tanh value head and a dense policy head, all in f32 whatever cfg.dtype says (the net is tiny)
+    bool simple = false;
+    DevBuf d1w, d1b, d2w, d2b, svw, svb, spw, spb;
     bool wait_spin = true;  // host wait for a batch: spinning hipStreamSynchronize, or a blocking event
     Act act = Act::F32;
     uint32_t hw = 0, bpad = 0, cpad0 = 0;
@@ -281,6 +285,10 @@ namespace {
 
 size_t blob_floats(const cattus_net_desc& d) {
     const size_t hw = (size_t)d.board * d.board, F = d.filters;
+    if (F == 0) {  // SimpleTwoHeadedModel: two K x K dense layers, a 1 x K and an M x K head
+        const size_t K = (size_t)d.planes * hw;
+        return 2 * (K * K + K) + K + 1 + (size_t)d.moves * K + d.moves;
+    }
     size_t n = F * d.planes * 9 + 4 * F;
     n += (size_t)d.blocks * (2 * F * F * 9 + 6 * F);
     n += (size_t)d.vhc * F + 2 * (size_t)d.vhc + (size_t)FC_HIDDEN * d.vhc * hw + FC_HIDDEN + FC_HIDDEN + 1;
@@ -349,8 +357,52 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
     return L.w.upload(w.data(), w.size() * 4);
 }
 
+// SimpleTwoHeadedModel: weights transposed to [k][n] (coalesced along n in the dense kernel), buffers for the planes tensor
+// and the two hidden layers.
+int build_simple(cattus_eval* e, const float* p) {
+    const cattus_net_desc& d = e->d;
+    const size_t K = (size_t)d.planes * e->hw, M = d.moves, B = e->cfg.max_batch;
+    auto upload_t = [&](DevBuf& buf, const float* w, size_t n_out) -> int {
+        std::vector<float> t(K * n_out);
+        for (size_t n = 0; n < n_out; n++)
+            for (size_t k = 0; k < K; k++) t[k * n_out + n] = w[n * K + k];
+        return buf.upload(t.data(), t.size() * 4);
+    };
+    int rc;
+    if ((rc = upload_t(e->d1w, p, K))) return rc;
+    p += K * K;
+    if ((rc = e->d1b.upload(p, K * 4))) return rc;
+    p += K;
+    if ((rc = upload_t(e->d2w, p, K))) return rc;
+    p += K * K;
+    if ((rc = e->d2b.upload(p, K * 4))) return rc;
+    p += K;
+    if ((rc = upload_t(e->svw, p, 1))) return rc;
+    p += K;
+    if ((rc = e->svb.upload(p, 4))) return rc;
+    p += 1;
+    if ((rc = upload_t(e->spw, p, M))) return rc;
+    p += M * K;
+    if ((rc = e->spb.upload(p, M * 4))) return rc;
+    for (Lane& L : e->lanes) {
+        HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventBlockingSync | hipEventDisableTiming));
+        if ((rc = L.d_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
+        if ((rc = L.x0.alloc(B * K * 4))) return rc;
+        if ((rc = L.a.alloc(B * K * 4))) return rc;
+        if ((rc = L.t.alloc(B * K * 4))) return rc;
+        if ((rc = L.d_policy.alloc(B * M * 4))) return rc;
+        if ((rc = L.d_value.alloc(B * 4))) return rc;
+        if ((rc = L.h_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
+        if ((rc = L.h_policy.alloc(B * M * 4))) return rc;
+        if ((rc = L.h_value.alloc(B * 4))) return rc;
+    }
+    return CATTUS_OK;
+}
+
 int build(cattus_eval* e, const float* p) {
     const cattus_net_desc& d = e->d;
+    if (e->simple) return build_simple(e, p);
     const uint32_t F = d.filters, hw = e->hw, FP = e->fpad;
     auto take = [&](size_t n) {
         const float* r = p;
@@ -499,6 +551,19 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
     };
     void *a = L.a.p, *t = L.t.p, *y = L.y.p;
     uint32_t nb = n;
+    if (e->simple) {
+        // SimpleTwoHeadedModel.forward (net_utils.py:112-121): flatten -> dense + ReLU -> dense + ReLU -> value: dense + tanh,
+        // policy: dense + the non-finite scrub of net/mod.rs:56-61
+        const uint32_t K = d.planes * hw;
+        launch_planes_to_tensor_nchw(d_planes, n, d.planes, w64, S, n, L.x0.as<float>(), st);
+        launch_dense(L.x0.as<float>(), K, e->d1w.as<float>(), e->d1b.as<float>(), n, K, K, (float*)a, 1, st);
+        launch_dense((float*)a, K, e->d2w.as<float>(), e->d2b.as<float>(), n, K, K, (float*)t, 1, st);
+        launch_dense((float*)t, K, e->svw.as<float>(), e->svb.as<float>(), n, K, 1, d_value, 2, st);
+        launch_dense((float*)t, K, e->spw.as<float>(), e->spb.as<float>(), n, K, d.moves, d_policy, 0, st);
+        hipError_t serr = hipGetLastError();
+        if (serr != hipSuccess) return fail(CATTUS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(serr));
+        return CATTUS_OK;
+    }
     if (e->tuned) {
         const uint32_t bpw = ROWS_PER_WG / e->slots;  // boards per workgroup of the conv kernel
         const uint32_t FP = e->fpad;
@@ -737,8 +802,10 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     memcpy(h, (const char*)weights + 8, sizeof h);
     if (h[0] != 1 || h[8] != FC_HIDDEN) return fail(CATTUS_E_INVALID, "unsupported blob version %u / hidden %u", h[0], h[8]);
     cattus_net_desc d{h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]};
-    if (d.board < 1 || d.board > 11 || !d.planes || !d.filters || !d.vhc || !d.phc || !d.moves)
+    const bool simple = d.filters == 0;  // SimpleTwoHeadedModel: no conv tower (cattus_amd/weights.py)
+    if (d.board < 1 || d.board > 11 || !d.planes || !d.moves || (!simple && (!d.vhc || !d.phc)) || (simple && (d.blocks || d.vhc || d.phc)))
         return fail(CATTUS_E_INVALID, "bad network shape in blob header");
+    if (simple && (size_t)d.planes * d.board * d.board > 2048) return fail(CATTUS_E_UNSUPPORTED, "SimpleTwoHeadedModel wider than 2048 features");
     if (nbytes != HEADER_BYTES + 4 * blob_floats(d)) return fail(CATTUS_E_INVALID, "blob size %zu does not match its header", nbytes);
     if (cfg->max_batch < 1 || cfg->max_batch > (1u << 20)) return fail(CATTUS_E_INVALID, "max_batch out of range");
     if ((uint64_t)cfg->plane_words * 64 < (uint64_t)d.board * d.board || cfg->plane_words > 2)
@@ -746,7 +813,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if (d.planes * cfg->plane_words > 128) return fail(CATTUS_E_UNSUPPORTED, "more than 128 plane words per leaf");
     if (cfg->dtype != CATTUS_DTYPE_F32 && cfg->dtype != CATTUS_DTYPE_BF16 && cfg->dtype != CATTUS_DTYPE_F16X2)
         return fail(CATTUS_E_INVALID, "unknown dtype %u", cfg->dtype);
-    if ((size_t)d.phc * d.board * d.board * 8 * 4 > 64 * 1024) return fail(CATTUS_E_UNSUPPORTED, "policy head too wide for the FC kernel");
+    if (!simple && (size_t)d.phc * d.board * d.board * 8 * 4 > 64 * 1024) return fail(CATTUS_E_UNSUPPORTED, "policy head too wide for the FC kernel");
 
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
@@ -796,8 +863,9 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     // the two 1x1 head convs share one 32-row MFMA tile.  Wider heads take the generic f32 path (one thread
     // per output, same arithmetic order), which otherwise serves as a checker only (CATTUS_FORCE_GENERIC=1).
     const char* force_generic = getenv("CATTUS_FORCE_GENERIC");
-    e->tuned = d.vhc + d.phc <= 32 && !(force_generic && force_generic[0] == '1');
-    e->act = cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16 : cfg->dtype == CATTUS_DTYPE_F16X2 ? Act::F16S : Act::F32;
+    e->simple = simple;
+    e->tuned = !simple && d.vhc + d.phc <= 32 && !(force_generic && force_generic[0] == '1');
+    e->act = simple ? Act::F32 : cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16 : cfg->dtype == CATTUS_DTYPE_F16X2 ? Act::F16S : Act::F32;
     if (!e->tuned && e->act != Act::F32)
         return fail(CATTUS_E_UNSUPPORTED, "bf16 / f16x2 need the MFMA tower: value + policy head channels <= 32 (got %u + %u)", d.vhc, d.phc);
     if (e->act == Act::F16S) {
@@ -997,6 +1065,7 @@ CATTUS_API int cattus_hip_stats(cattus_eval* e, cattus_stats* out) {
 CATTUS_API int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, float* avg_launch_us, uint32_t* launches) {
     if (!e || !avg_launch_us || !launches) return fail(CATTUS_E_INVALID, "NULL argument");
     if (n < 1 || n > e->cfg.max_batch || reps < 1) return fail(CATTUS_E_INVALID, "bad n/reps");
+    if (e->simple) return fail(CATTUS_E_UNSUPPORTED, "a SimpleTwoHeadedModel has no conv tower to time");
     Lane& L = e->lanes[0];
     std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));

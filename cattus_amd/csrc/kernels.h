@@ -137,5 +137,10 @@ int launch_legal_softmax(const float* policy, uint32_t M, const uint16_t* idx, c
                          float* probs, hipStream_t st);
 void launch_policy_fc(const float* hv, uint32_t hv_stride, uint32_t off, const float* wpt, const float* bp, uint32_t b,
                       uint32_t K, uint32_t M, float* policy, hipStream_t st);
+// One dense layer of SimpleTwoHeadedModel (training/cattus_train/net_utils.py:92-121), f32, the term order of every
+// other dot product here: y[b][n] = epi(sum_k wt[k][n] * x[b * x_stride + k] + bias[n]); epi 0: non-finite -> f32::MIN
+// (policy logits), 1: ReLU, 2: tanh.  K * 32 bytes of LDS (K <= 2048).
+void launch_dense(const float* x, uint32_t x_stride, const float* wt, const float* bias, uint32_t b, uint32_t K, uint32_t N,
+                  float* y, int epi, hipStream_t st);
 
 }  // namespace cattus

@@ -2061,6 +2061,8 @@ int launch_legal_softmax(const float* policy, uint32_t M, const uint16_t* idx, c
 // Block = 256 logits x 8 leaves; the 8 input rows are staged in LDS, every weight is loaded once
 // (coalesced along m) and used for 8 fmaf.
 constexpr int PFC_ROWS = 8;
+enum { DENSE_SCRUB = 0, DENSE_RELU = 1, DENSE_TANH = 2 };  // what follows `+ bias`
+template <int EPI>
 __global__ void __launch_bounds__(256) policy_fc_kernel(const float* __restrict__ hv, uint32_t hv_stride, uint32_t off,
                                                         const float* __restrict__ wpt, const float* __restrict__ bp,
                                                         uint32_t nb, uint32_t K, uint32_t M, float* __restrict__ policy) {
@@ -2090,8 +2092,14 @@ __global__ void __launch_bounds__(256) policy_fc_kernel(const float* __restrict_
     for (int rr = 0; rr < PFC_ROWS; rr++) {
         if (b0 + rr >= nb) break;
         float y = acc[rr] + bias;
-        // non-finite logits -> f32::MIN (reference: engine/src/net/mod.rs:56-61)
-        if (!(__builtin_fabsf(y) <= 3.40282347e+38f)) y = -3.40282347e+38f;
+        if constexpr (EPI == DENSE_SCRUB) {
+            // non-finite logits -> f32::MIN (reference: engine/src/net/mod.rs:56-61)
+            if (!(__builtin_fabsf(y) <= 3.40282347e+38f)) y = -3.40282347e+38f;
+        } else if constexpr (EPI == DENSE_RELU) {
+            y = y > 0.0f ? y : 0.0f;
+        } else {
+            y = tanh_exact(y);
+        }
         policy[(size_t)(b0 + rr) * M + m] = y;
     }
 }
@@ -2100,8 +2108,19 @@ void launch_policy_fc(const float* hv, uint32_t hv_stride, uint32_t off, const f
                       uint32_t K, uint32_t M, float* policy, hipStream_t st) {
     if (!b) return;
     const dim3 grid((M + 255) / 256, (b + PFC_ROWS - 1) / PFC_ROWS), block(256);
-    hipLaunchKernelGGL(policy_fc_kernel, grid, block, PFC_ROWS * K * sizeof(float), st, hv, hv_stride, off, wpt, bp, b, K,
+    hipLaunchKernelGGL(policy_fc_kernel<DENSE_SCRUB>, grid, block, PFC_ROWS * K * sizeof(float), st, hv, hv_stride, off, wpt, bp, b, K,
                        M, policy);
+}
+
+// A dense layer of SimpleTwoHeadedModel (net_utils.py:92-121) on the same kernel: y[b][n] = epi(sum_k wt[k][n] x[b][k] + bias[n])
+void launch_dense(const float* x, uint32_t x_stride, const float* wt, const float* bias, uint32_t b, uint32_t K, uint32_t N,
+                  float* y, int epi, hipStream_t st) {
+    if (!b) return;
+    const dim3 grid((N + 255) / 256, (b + PFC_ROWS - 1) / PFC_ROWS), block(256);
+    const size_t lds = PFC_ROWS * K * sizeof(float);
+    if (epi == DENSE_RELU) hipLaunchKernelGGL(policy_fc_kernel<DENSE_RELU>, grid, block, lds, st, x, x_stride, 0u, wt, bias, b, K, N, y);
+    else if (epi == DENSE_TANH) hipLaunchKernelGGL(policy_fc_kernel<DENSE_TANH>, grid, block, lds, st, x, x_stride, 0u, wt, bias, b, K, N, y);
+    else hipLaunchKernelGGL(policy_fc_kernel<DENSE_SCRUB>, grid, block, lds, st, x, x_stride, 0u, wt, bias, b, K, N, y);
 }
 
 }  // namespace cattus

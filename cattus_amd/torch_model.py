@@ -60,8 +60,25 @@ class PolicyValueNet(nn.Module):
         return p, v
 
     @classmethod
-    def from_blob(cls, blob: bytes) -> "PolicyValueNet":
+    def from_blob(cls, blob: bytes):
         d, sd = state_dict_from_blob(blob)
-        net = cls(d)
+        net = SimpleTwoHeaded(d) if d.simple else cls(d)
         net.load_state_dict(sd, strict=True)
         return net.eval()
+
+
+class SimpleTwoHeaded(nn.Module):
+    """The reference's other ``model.type`` (``SimpleTwoHeadedModel``, net_utils.py:92-121) with its checkpoint's key names."""
+
+    def __init__(self, d: NetDesc):
+        super().__init__()
+        self.desc = d
+        k = d.features
+        self._dense1 = nn.Linear(k, k)
+        self._dense2 = nn.Linear(k, k)
+        self._value_head = nn.Linear(k, 1)
+        self._policy_head = nn.Linear(k, d.moves)
+
+    def forward(self, x):
+        flow = torch.relu(self._dense2(torch.relu(self._dense1(x.flatten(1)))))
+        return self._policy_head(flow), torch.tanh(self._value_head(flow))

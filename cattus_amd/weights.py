@@ -42,8 +42,21 @@ class NetDesc:
     def hw(self) -> int:
         return self.board * self.board
 
+    @property
+    def simple(self) -> bool:
+        """``SimpleTwoHeadedModel`` (net_utils.py:92-121: two dense layers and two dense heads on the flattened planes), the
+        reference's other ``model.type``; encoded as ``filters == 0`` (no conv tower)."""
+        return self.filters == 0
+
+    @property
+    def features(self) -> int:
+        return self.planes * self.hw
+
     def flops_per_position(self) -> int:
         """2*MAC count, BN/activations excluded."""
+        if self.simple:
+            k = self.features
+            return 2 * k * k * 2 + 2 * k + 2 * k * self.moves
         c, f, n, hw = self.planes, self.filters, self.blocks, self.hw
         return (
             2 * c * f * 9 * hw
@@ -74,8 +87,25 @@ def hex_game(size: int) -> dict:
     return dict(planes=3, board=size, moves=size * size)
 
 
+def simple_desc(planes: int, board: int, moves: int) -> NetDesc:
+    """Shape of a ``SimpleTwoHeadedModel`` for a game (net_utils.py:92-104)."""
+    return NetDesc(planes, board, moves, 0, 0, 0, 0)
+
+
 def tensor_specs(d: NetDesc) -> list[tuple[str, tuple[int, ...]]]:
     """(state_dict key, shape) in blob order."""
+    if d.simple:  # net_utils.py:101-110
+        k = d.features
+        return [
+            ("_dense1.weight", (k, k)),
+            ("_dense1.bias", (k,)),
+            ("_dense2.weight", (k, k)),
+            ("_dense2.bias", (k,)),
+            ("_value_head.weight", (1, k)),
+            ("_value_head.bias", (1,)),
+            ("_policy_head.weight", (d.moves, k)),
+            ("_policy_head.bias", (d.moves,)),
+        ]
     f, hw = d.filters, d.hw
     specs: list[tuple[str, tuple[int, ...]]] = [
         ("_conv1._conv.weight", (f, d.planes, 3, 3)),
@@ -168,6 +198,11 @@ def desc_from_state_dict(state_dict, board: int) -> NetDesc:
     """The network's shape read off a ConvNetV1 ``state_dict`` (net_utils.py:45-89): planes / filters from the stem conv,
     blocks from the residual keys, head widths and move count from the head layers."""
     shape = lambda k: tuple(state_dict[k].shape)  # noqa: E731
+    if "_dense1.weight" in state_dict:  # SimpleTwoHeadedModel
+        k, moves = shape("_dense1.weight")[0], shape("_policy_head.weight")[0]
+        if k % (board * board) != 0:
+            raise ValueError("state_dict does not belong to a SimpleTwoHeadedModel on a %dx%d board" % (board, board))
+        return simple_desc(k // (board * board), board, moves)
     filters, planes = shape("_conv1._conv.weight")[:2]
     blocks = 0
     while f"_residual_blocks.{blocks}._conv1.weight" in state_dict:
@@ -249,7 +284,7 @@ def seeded_tensors(d: NetDesc, seed: int) -> dict[str, np.ndarray]:
             t = 0.2 * u - 0.1
         else:
             fan_in = int(np.prod(shape[1:]))
-            gain = 0.5 if "_head.2." in name or "_head.4." in name else 1.0  # keep tanh unsaturated
+            gain = 0.5 if "_head.2." in name or "_head.4." in name or name.startswith("_value_head.w") else 1.0  # keep tanh unsaturated
             b = np.float32(gain * np.sqrt(3.0 / fan_in))
             t = (2.0 * u - 1.0) * b
         out[name] = t.astype(np.float32).reshape(shape)

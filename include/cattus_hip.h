@@ -66,7 +66,9 @@ typedef struct cattus_stats {
     double run_seconds_total;
 } cattus_stats;
 
-/* Network shape as stored in the weight blob header (cattus_amd/weights.py). */
+/* Network shape as stored in the weight blob header (cattus_amd/weights.py).  filters == 0 (with blocks = vhc = phc = 0) is
+ * the reference's other model type, SimpleTwoHeadedModel (training/cattus_train/net_utils.py:92-121: two dense layers and two
+ * dense heads on the flattened planes); it is evaluated in f32 whatever dtype is configured. */
 typedef struct cattus_net_desc {
     uint32_t planes, board, moves, blocks, filters, vhc, phc, fc_hidden;
 } cattus_net_desc;

@@ -67,6 +67,8 @@ typedef struct oracle_net {
     float *vconv_w, *vconv_b; /* [vhc][F], [vhc] folded */
     float *pconv_w, *pconv_b; /* [phc][F], [phc] folded */
     const float *vfc1_w, *vfc1_b, *vfc2_w, *vfc2_b, *pfc_w, *pfc_b; /* into blob copy */
+    /* SimpleTwoHeadedModel (training/cattus_train/net_utils.py:92-121; blob with F == 0): into the blob copy */
+    const float *d1_w, *d1_b, *d2_w, *d2_b, *sv_w, *sv_b, *sp_w, *sp_b;
     float *blob; /* owned copy of tensor payload */
 } oracle_net;
 
@@ -177,6 +179,10 @@ static int make_conv3(conv3_layer *L, const float **p, uint32_t cout, uint32_t c
 ORACLE_API size_t oracle_blob_nbytes(uint32_t C, uint32_t S, uint32_t M, uint32_t blocks, uint32_t F,
                                      uint32_t vhc, uint32_t phc) {
     size_t hw = (size_t)S * S, n = 0;
+    if (F == 0) { /* SimpleTwoHeadedModel: two K x K dense layers, a 1 x K and an M x K head, K = C * hw */
+        const size_t K = (size_t)C * hw;
+        return HEADER_BYTES + 4 * (2 * (K * K + K) + K + 1 + (size_t)M * K + M);
+    }
     n += (size_t)F * C * 9 + 4 * (size_t)F;
     n += (size_t)blocks * (2 * (size_t)F * F * 9 + 6 * (size_t)F);
     n += (size_t)vhc * F + 2 * (size_t)vhc + 128 * vhc * hw + 128 + 128 + 1;
@@ -210,7 +216,8 @@ ORACLE_API oracle_net *oracle_net_create(const void *blob, size_t nbytes) {
     memcpy(h, (const char *)blob + 8, sizeof h);
     if (h[0] != 1 || h[8] != 128) return NULL;
     oracle_desc d = {h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]};
-    if (d.S < 1 || d.S > MAX_S || d.C < 1 || d.F < 1 || d.vhc < 1 || d.phc < 1) return NULL;
+    if (d.S < 1 || d.S > MAX_S || d.C < 1 || d.M < 1) return NULL;
+    if (d.F != 0 && (d.vhc < 1 || d.phc < 1)) return NULL;
     if (nbytes != oracle_blob_nbytes(d.C, d.S, d.M, d.blocks, d.F, d.vhc, d.phc)) return NULL;
 
     oracle_net *net = (oracle_net *)calloc(1, sizeof *net);
@@ -222,6 +229,14 @@ ORACLE_API oracle_net *oracle_net_create(const void *blob, size_t nbytes) {
     const float *p = net->blob;
     uint32_t hw = d.S * d.S;
 
+    if (d.F == 0) { /* SimpleTwoHeadedModel: state_dict order _dense1, _dense2, _value_head, _policy_head */
+        const size_t K = (size_t)d.C * hw;
+        net->d1_w = take(&p, K * K), net->d1_b = take(&p, K);
+        net->d2_w = take(&p, K * K), net->d2_b = take(&p, K);
+        net->sv_w = take(&p, K), net->sv_b = take(&p, 1);
+        net->sp_w = take(&p, (size_t)d.M * K), net->sp_b = take(&p, d.M);
+        return net;
+    }
     if (make_conv3(&net->stem, &p, d.F, d.C, 1)) goto fail;
     net->c1 = (conv3_layer *)calloc(d.blocks ? d.blocks : 1, sizeof(conv3_layer));
     net->c2 = (conv3_layer *)calloc(d.blocks ? d.blocks : 1, sizeof(conv3_layer));
@@ -400,6 +415,29 @@ static int forward_one(const oracle_net *net, const uint64_t *planes, uint32_t w
                        float *value, float *stem_out, float *tower_out) {
     const oracle_desc *d = &net->d;
     const uint32_t hw = d->S * d->S, F = d->F;
+    if (F == 0) {
+        /* SimpleTwoHeadedModel.forward (net_utils.py:112-121): flatten (C-major: c * hw + p) -> dense + ReLU -> dense + ReLU ->
+         * value: dense + tanh; policy: dense (raw logits) + the scrub of net/mod.rs:56-61.  Same chain order as every other
+         * dot product of this file (8-groups of k ascending, 0,4,1,5,2,6,3,7 inside). */
+        if (stem_out || tower_out) return -1;
+        const uint32_t K = d->C * hw;
+        float *x = (float *)calloc(3 * (size_t)K, sizeof(float));
+        if (!x) return -1;
+        float *h1 = x + K, *h2 = x + 2 * K, v;
+        for (uint32_t c = 0; c < d->C; c++)
+            for (uint32_t i = 0; i < hw; i++) x[c * hw + i] = plane_bit(planes + (size_t)c * w64, i) ? 1.0f : 0.0f;
+        linear(net->d1_w, net->d1_b, K, K, x, h1);
+        for (uint32_t j = 0; j < K; j++) h1[j] = h1[j] > 0.0f ? h1[j] : 0.0f;
+        linear(net->d2_w, net->d2_b, K, K, h1, h2);
+        for (uint32_t j = 0; j < K; j++) h2[j] = h2[j] > 0.0f ? h2[j] : 0.0f;
+        linear(net->sv_w, net->sv_b, 1, K, h2, &v);
+        *value = oracle_tanhf(v);
+        linear(net->sp_w, net->sp_b, d->M, K, h2, policy);
+        for (uint32_t m = 0; m < d->M; m++)
+            if (!isfinite(policy[m])) policy[m] = -3.40282347e+38f; /* f32::MIN */
+        free(x);
+        return 0;
+    }
     float *x0 = (float *)malloc(sizeof(float) * d->C * hw);
     float *a = (float *)malloc(sizeof(float) * F * hw);
     float *t = (float *)malloc(sizeof(float) * F * hw);
