@@ -190,6 +190,7 @@ bool is_pinned(const void* p) {
 
 struct ConvLayer {
     DevBuf w, b;
+    DevBuf wf;  // f16x2: the same weights in MFMA fragment order (kernels.h, CONV_W_FRAG)
     uint32_t cin = 0;  // as laid out on the device (padded for the MFMA path)
 };
 
@@ -242,6 +243,7 @@ struct cattus_eval {
     DevBuf t64_layers;
     bool pack_separately = false;  // CATTUS_FUSED_STEM=0: plane pack as its own launch in front of the stem (A/B, tests)
     int t64_force_ch = 0;          // CATTUS_T64_CH=2|4: workgroup shape of the resident tower (A/B runs, the row-split test)
+    bool split_wfrag = true;       // CATTUS_SPLIT_W=0: f16x2 weights through the LDS ring (conv3x3_split_kernel) instead of the register ring
     bool t64_layer_steps = true;   // CATTUS_T64_LS=0: three barriers per layer in the one-board resident tower
     int device = 0;
 
@@ -337,6 +339,18 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
                 }
         }
         if ((rc = L.b.upload(b.data(), b.size() * sizeof(float)))) return rc;
+        if (e->split_wfrag) {  // the register-ring kernel's layout: a permutation of the rows above
+            std::vector<_Float16> wf(w.size());
+            for (uint32_t t = 0; t < 9; t++)
+                for (uint32_t co = 0; co < cout_pad; co++) {
+                    const _Float16* row = &w[((size_t)t * cout_pad + co) * 2 * cin_pad];
+                    for (uint32_t ci = 0; ci < cin_pad; ci++) {
+                        wf[split_frag_index(t, co, ci, 0, cin_pad)] = row[(size_t)(ci >> 5) * 64 + (ci & 31)];
+                        wf[split_frag_index(t, co, ci, 1, cin_pad)] = row[(size_t)(ci >> 5) * 64 + (ci & 31) + 32];
+                    }
+                }
+            return L.wf.upload(wf.data(), wf.size() * 2);
+        }
         return L.w.upload(w.data(), w.size() * 2);
     }
     std::vector<float> b(cout_pad, 0.0f);
@@ -587,15 +601,19 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             if (!fused_stem) launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
             hipEvent_t s0 = ev(false), s1 = ev(true);
             // the split tower hands its last layer to the f32 head kernels as plain f32 rows
-            const int last_flags = e->act == Act::F16S ? 1 : 0;
-            launch_conv3x3_mfma(e->act, L.x0.p, e->stem.w.p, e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
-                                fused_stem ? &stem_in : nullptr, d.blocks == 0 ? last_flags : 0);
+            const int last_flags = e->act == Act::F16S ? CONV_OUT_F32 : 0;
+            const bool wfrag = e->act == Act::F16S && e->split_wfrag;
+            const int wflag = wfrag ? CONV_W_FRAG : 0;
+            auto wptr = [&](const ConvLayer& c) { return wfrag ? c.wf.p : c.w.p; };
+            launch_conv3x3_mfma(e->act, L.x0.p, wptr(e->stem), e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
+                                fused_stem ? &stem_in : nullptr, wflag | (d.blocks == 0 ? last_flags : 0));
             for (uint32_t i = 0; i < d.blocks; i++) {
                 s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, a, e->c1[i]->w.p, e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1);
+                launch_conv3x3_mfma(e->act, a, wptr(*e->c1[i]), e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1, nullptr,
+                                    wflag);
                 s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, t, e->c2[i]->w.p, e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1, nullptr,
-                                    i + 1 == d.blocks ? last_flags : 0);
+                launch_conv3x3_mfma(e->act, t, wptr(*e->c2[i]), e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1, nullptr,
+                                    wflag | (i + 1 == d.blocks ? last_flags : 0));
                 std::swap(a, y);
             }
         }
@@ -847,6 +865,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     const char* fused_stem_env = getenv("CATTUS_FUSED_STEM");
     const char* t64_ch_env = getenv("CATTUS_T64_CH");
     const char* t64_ls_env = getenv("CATTUS_T64_LS");
+    const char* split_w_env = getenv("CATTUS_SPLIT_W");
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
     if (!e) return fail(CATTUS_E_NOMEM, "out of memory");
@@ -858,6 +877,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->pack_separately = fused_stem_env && fused_stem_env[0] == '0';
     e->t64_force_ch = t64_ch_env ? atoi(t64_ch_env) : 0;
     e->t64_layer_steps = !(t64_ls_env && atoi(t64_ls_env) == 0);
+    e->split_wfrag = !(split_w_env && split_w_env[0] == '0');
     e->hw = d.board * d.board;
     // The MFMA tower covers every board up to 11x11 and any filter count (channels are padded to 64 with zeros);
     // the two 1x1 head convs share one 32-row MFMA tile.  Wider heads take the generic f32 path (one thread

@@ -45,7 +45,17 @@ struct StemInput {
 // Act::F16S (split precision): rows of in / res / out and of w are f16 pairs interleaved in groups of 32 channels,
 // [hi of channels 32g .. 32g+31 | lo of the same 32] per 128 bytes; w is pre-scaled per output channel by a power of
 // two, bias is [cout biases | cout inverse scales]; cin counts channels (pairs).
-// flags & 1 (F16S only): out is written as plain f32 [row][cout] (last tower layer, read by the f32 head kernels).
+// flags & CONV_OUT_F32 (F16S only): out is written as plain f32 [row][cout] (last tower layer, read by the f32 head kernels).
+// flags & CONV_W_FRAG (F16S only): w is in MFMA fragment order, [cout / 32][stage][hi | lo][lane][8 f16] with
+// stage = ((chunk * 3 + dy) * 3 + dx) * 2 + k-half (split_frag_index below): the kernel that keeps the weights in a register
+// ring instead of LDS.  Non-stem layers then need cin >= 64.
+constexpr int CONV_OUT_F32 = 1, CONV_W_FRAG = 2;
+// Element index of weight (tap t, output channel co, input channel ci, part 0 = hi / 1 = lo) in fragment order.
+inline size_t split_frag_index(uint32_t t, uint32_t co, uint32_t ci, uint32_t part, uint32_t cin_pad) {
+    const uint32_t nst = cin_pad / 32 * 18, ch = ci >> 5, k = (ci >> 4) & 1, h = (ci >> 3) & 1, e = ci & 7;
+    const uint32_t stage = ((ch * 3 + t / 3) * 3 + t % 3) * 2 + k, lane = h * 32 + (co & 31);
+    return ((((size_t)(co >> 5) * nst + stage) * 2 + part) * 64 + lane) * 8 + e;
+}
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const StemInput* stem = nullptr,

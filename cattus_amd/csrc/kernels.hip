@@ -21,6 +21,7 @@
 #include <hip/hip_ext.h>
 
 #include <atomic>
+#include <type_traits>
 
 namespace cattus {
 
@@ -652,7 +653,6 @@ void set_conv_cb(int v) { g_conv_cb = (v == 1 || v == 2) ? v : 0; }
 //   * a consumer stage is (tap, 16 channels): the hi and lo fragments of 2 weight blocks and 2 pixel blocks (8
 //     ds_read_b128) feed 12 MFMAs, one stage (384 cycles of MFMA issue) of look-ahead.
 // flags & CONV_OUT_F32: the output is written as plain f32 [row][cout] (the last tower layer, for the f32 head kernels).
-constexpr int CONV_OUT_F32 = 1;
 constexpr int SP = 144;                                 // LDS row pitch
 constexpr int SP_TAP = 64 * SP;                         // the 64 cout rows of one tap
 constexpr int SP_SLAB = 3 * SP_TAP;                     // 27,648 B = 27 LDS-DMA pieces of 1 KiB
@@ -985,6 +985,386 @@ __global__ void __launch_bounds__(512, 2)
     STAMP_FLUSH(wave);
 }
 
+// ------------------------------------------------------------------------------------------
+// K1s': the split-precision conv with the WEIGHT fragments taken straight from L2 into a register ring
+// ------------------------------------------------------------------------------------------
+//
+// conv3x3_split_kernel moves every operand byte through LDS twice (LDS-DMA write, ds_read): at three MFMA terms per
+// product its LDS port is ~90 % busy while the matrix pipe is ~60 % busy, and the 3-slab weight ring costs a barrier --
+// with a drained fragment pipeline behind it -- per (chunk, kernel row).  Here only the ACTIVATIONS live in LDS.  The
+// weights are uploaded a second time in MFMA fragment order ([32-cout block][stage][hi | lo][lane][8 f16], 2 KiB per
+// block and stage, stage = ((chunk * 3 + dy) * 3 + dx) * 2 + k-half), so that a consumer wave's operand for one stage is
+// CB x 2 fully coalesced global_load_dwordx4; it keeps SW_D stages in flight in registers (hand-placed loads and
+// vmcnt waits: the compiler's own placement sinks a refill down to its use).  The four consumer waves of a workgroup
+// fetch the same bytes within a few hundred cycles of each other (L1 / L2 hits: scripts/probes/bdirect_probe.hip ->
+// profiles/r03_bdirect_probe.txt measured this loop at 61.5 k cycles against 70.1 k for the ring in LDS, MFMA floor 55.3 k).
+//
+// What is left for the loader waves: the activation chunks (two buffers) and the layer's skip rows, which now go to
+// LDS as well (64 KiB at CB = 2) instead of sitting in 64 VGPRs of every consumer lane through the whole loop.
+// Hand-off: ONE barrier per chunk, in front of the chunk's last stage.  A stage's pixel fragments are read one stage ahead,
+// so a consumer that has waited for its LDS reads there has read everything it will ever read of the chunk -- the loaders
+// may refill the buffer with chunk + 2, a whole chunk (6.9 k cycles of MFMA issue) before it is needed -- and the loaders
+// arrive only after chunk + 1 has landed, so the last stage's look-ahead reads cross into the next chunk and the fragment
+// pipeline never drains at a barrier.
+// The MFMA sequence per accumulator is that of conv3x3_split_kernel, so the two kernels agree bit for bit.
+constexpr int SW_D = 6;                       // weight stages in flight per consumer wave; divides the 18 stages of a chunk
+constexpr int SW_STAGE = 2048;                // bytes per 32-cout block and stage: hi fragment, lo fragment
+constexpr int SW_LDS_SKIP = 2 * SP_ABUF;      // skip rows behind the two activation buffers
+constexpr int sw_lds_total(int cb) { return SW_LDS_SKIP + 256 * 32 * cb * 4; }  // 139,552 B at CB = 2
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <bool HAS_RES, bool BIG, bool STEM, int CB>
+__global__ void __launch_bounds__(512, 2)
+    conv3x3_splitw_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wf, const float* __restrict__ bias,
+                          const _Float16* __restrict__ res, _Float16* __restrict__ out, int cin, int cout, int S, int flags,
+                          StemPlanes<STEM> sp) {
+    typedef _Float16 T;
+    typedef Mfma<T>::frag frag;
+    constexpr int KC = 32;        // channels (pairs) per 128-byte chunk
+    constexpr int CPW = 32 * CB;  // output channels of this workgroup
+    constexpr int D = SW_D;
+    constexpr int SKIP_ROW = CPW * 4;   // bytes of a skip row: [32 hi | 32 lo] per 32 couts
+    constexpr int SKIP_PPW = 8 * CB;    // 1 KiB pieces of the skip rows per loader wave
+    static_assert(18 % D == 0, "a chunk's 18 stages must map onto whole turns of the ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const bool is_loader = wave >= 4;
+    STAMP_DECL;
+    STAMP(0);
+    STAMP_RT(5);
+
+    const int nblk = gridDim.x, ncb = cout / CPW;
+    int logical = blockIdx.x;
+    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int cout0 = (logical % ncb) * CPW;
+    const int row0 = (logical / ncb) * ROWS_PER_WG;
+
+    if (tid < 18) reinterpret_cast<f32x4*>(smem + (tid / 9) * SP_ABUF + SP_ZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero rows are written before the first barrier
+
+    const int nch = cin / KC;
+    const int nst = nch * 18;
+    const uint32_t row_bytes = (uint32_t)cin * 4;
+
+    if (is_loader) {
+        // ================================ loader waves ================================
+        // their few LDS-DMA instructions share the vector-memory issue path with the consumers' weight loads (16 KiB per
+        // stage and CU): let them go first
+        __builtin_amdgcn_s_setprio(3);
+        const int lw = wave - 4;
+        uint32_t off_a[2][SP_APL];
+        int dst_a[2][SP_APL];
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int i = 0; i < SP_APL; i++) {  // the padded image of a chunk, as in conv3x3_split_kernel
+                const int id = g * 18 + min(lw * SP_APL + i, 17);
+                const int sidx = id * 64 + lane, irow = sidx / 9, c = min(sidx - irow * 9, 7);
+                off_a[g][i] = (uint32_t)irow * row_bytes + c * 16;
+                dst_a[g][i] = id * 1024;
+            }
+        const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
+        auto issue_chunk = [&](int ch) {  // activation chunk ch -> buffer ch & 1
+            const char* src = abase0 + (size_t)ch * 128;
+            char* dst = smem + (ch & 1) * SP_ABUF;
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int i = 0; i < SP_APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
+        };
+        if constexpr (STEM) {
+            // K0 fused (one chunk, no DMA): this thread expands pixel row (lw * 64 + lane) of the workgroup's 256 rows
+            constexpr int MAXC = 32;
+            const int row = lw * 64 + lane;
+            const uint32_t grow = (uint32_t)(row0 + row), slots = BIG ? 128u : 64u;
+            const uint32_t board = grow / slots, px = grow % slots;
+            const bool live = board < sp.n && (int)px < S * S;
+            typedef const __attribute__((address_space(1))) uint64_t* gu64p;
+            const gu64p pl = (gu64p)(sp.planes + (size_t)(live ? board : 0) * sp.C * sp.w64 + (live ? (px >> 6) : 0));
+            uint64_t words[MAXC];
+#pragma unroll
+            for (int c = 0; c < MAXC; c++) words[c] = (live && (uint32_t)c < sp.C) ? pl[(size_t)c * sp.w64] : 0ull;
+            char* dstrow = smem + row * SP;
+#pragma unroll
+            for (int sl = 0; sl < 8; sl++) {
+                T vals[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int c = sl * 8 + i;
+                    vals[i] = (c < MAXC && ((words[c < MAXC ? c : 0] >> (px & 63)) & 1ull)) ? (T)1.0f : (T)0.0f;
+                }
+                *reinterpret_cast<f32x4*>(dstrow + sl * 16) = *reinterpret_cast<f32x4*>(vals);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // P
+        } else {
+            issue_chunk(0);
+            wait_vm_barrier<0>();  // P: chunk 0 has landed
+            issue_chunk(1);        // the host guarantees at least two chunks (cin is a multiple of 64)
+            if constexpr (HAS_RES) {
+                // skip rows: byte q of the LDS image is byte q % SKIP_ROW of row q / SKIP_ROW of the workgroup's rows of `res`;
+                // requested behind chunk 1, they have until the second barrier (nothing reads them before the epilogue)
+                const char* rbase = reinterpret_cast<const char*>(res) + ((size_t)row0 * cout + cout0) * 4;
+#pragma unroll
+                for (int i = 0; i < SKIP_PPW; i++) {
+                    const int pc = lw * SKIP_PPW + i;
+                    const int q = pc * 1024 + lane * 16, row = q / SKIP_ROW, col = q % SKIP_ROW;
+                    glds16(rbase + (size_t)row * cout * 4 + col, smem + SW_LDS_SKIP + pc * 1024);
+                }
+            }
+        }
+        STAMP(1);
+        for (int ch = 0; ch < nch; ch++) {
+            {
+                // chunk ch + 1 has landed (the younger skip rows may still be in flight at the first barrier)
+#ifdef CATTUS_STAMPS
+                const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+                if (HAS_RES && ch == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SKIP_PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+                asm volatile("s_barrier" ::: "memory");
+                st_[4] += t1_ - t0_;
+                st_[7] += __builtin_amdgcn_s_memtime() - t1_;
+#else
+                if (HAS_RES && ch == 0) wait_vm_barrier<SKIP_PPW>();
+                else wait_vm_barrier<0>();
+#endif
+            }
+            if (ch + 2 < nch) issue_chunk(ch + 2);  // every consumer has read chunk ch: its buffer is free
+        }
+        STAMP(2);
+        STAMP(3);
+        STAMP_RT(6);
+        STAMP_FLUSH(wave);
+        return;
+    }
+
+    // ================================ consumer waves ================================
+    // weight ring: slot d holds the CB x (hi, lo) fragments of stage s with s % D == d
+    const char* wblk = reinterpret_cast<const char*>(wf) + (size_t)(cout0 >> 5) * nst * SW_STAGE;
+    const uint32_t voff0 = lane * 16, voff1 = lane * 16 + (uint32_t)nst * SW_STAGE;
+    u32x4 ring[D][CB * 2];
+    auto load_stage = [&](u32x4(&slot)[CB * 2], const char* p) {
+        if constexpr (CB == 2) {
+            u32x4 l0, l1, l2, l3;
+            asm volatile(
+                "global_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:1024\n\t"
+                "global_load_dwordx4 %2, %5, %6\n\tglobal_load_dwordx4 %3, %5, %6 offset:1024"
+                : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+                : "v"(voff0), "v"(voff1), "s"(p)
+                : "memory");
+            slot[0] = l0, slot[1] = l1, slot[2] = l2, slot[3] = l3;
+        } else {
+            u32x4 l0, l1;
+            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                         : "=&v"(l0), "=&v"(l1)
+                         : "v"(voff0), "s"(p)
+                         : "memory");
+            slot[0] = l0, slot[1] = l1;
+        }
+    };
+    // all but the n youngest loads have returned; the asm owns the registers, so nothing reads them before the wait
+    // (n is a constant once the stage loop is unrolled; the immediate has to be a literal)
+    auto wait_stage = [&](u32x4(&slot)[CB * 2], int n) {
+#define CATTUS_WAIT_CASE(N)                                                                                       \
+    case N:                                                                                                       \
+        if constexpr (CB == 2) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)); \
+        else asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r0), "+v"(r1));                                        \
+        break;
+        u32x4 r0 = slot[0], r1 = slot[1], r2 = slot[CB == 2 ? 2 : 0], r3 = slot[CB == 2 ? 3 : 1];
+        switch (n) {
+            CATTUS_WAIT_CASE(0)
+            CATTUS_WAIT_CASE(2)
+            CATTUS_WAIT_CASE(4)
+            CATTUS_WAIT_CASE(6)
+            CATTUS_WAIT_CASE(8)
+            CATTUS_WAIT_CASE(10)
+            CATTUS_WAIT_CASE(12)
+            CATTUS_WAIT_CASE(16)
+            CATTUS_WAIT_CASE(20)
+            default: __builtin_trap();
+        }
+#undef CATTUS_WAIT_CASE
+        slot[0] = r0, slot[1] = r1;
+        if constexpr (CB == 2) slot[2] = r2, slot[3] = r3;
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    // epilogue operands first (ordinary loads, older than every ring load: the hand-counted waits below stay exact)
+    constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = 64 / RPT;
+    const int prow = lane / LPR, cg = lane % LPR;
+    f32x4 bias8[2], ds8[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        bias8[q] = *reinterpret_cast<const f32x4*>(bias + cout0 + cg * 8 + q * 4);
+        ds8[q] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cg * 8 + q * 4);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < D; d++) load_stage(ring[d], wblk + (size_t)d * SW_STAGE);
+
+    const int pslot0 = BIG ? (wave & 1) * 64 : 0;
+    const int board_row = BIG ? (wave >> 1) * 128 : wave * 64;  // first LDS row of this wave's board
+    int rowa[9][2];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) {
+        const int p = pslot0 + pb * 32 + r;
+        const int ph_ = p / S, pw = p - ph_ * S;
+        const bool pvalid = p < S * S;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; t9++) {
+            const int hh = ph_ + t9 / 3 - 1, ww = pw + t9 % 3 - 1;
+            const bool ok = pvalid && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
+            rowa[t9][pb] = (ok ? (board_row + hh * S + ww) * SP : SP_ZERO) + h * 16;
+        }
+    }
+
+    f32x16 acc[CB][2];
+#pragma unroll
+    for (int i = 0; i < CB; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    const size_t orow = (size_t)cout * 2;  // elements of T per row of `res` / `out`
+    const int ocol = ((cout0 + cg * 8) >> 5) * 64 + ((cout0 + cg * 8) & 31);  // hi values of the lane's 8 couts; lo 32 further
+
+    {
+        STAMP_ACC_BEGIN;
+        asm volatile("s_barrier" ::: "memory");  // P: chunk 0 is in buffer 0
+        STAMP_ACC_END(4);
+    }
+    STAMP(1);
+    // pixel fragments: [stage parity][pixel block]
+    frag ph[2][2], pl[2][2];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) {
+        ph[0][pb] = *reinterpret_cast<const frag*>(smem + rowa[0][pb]);
+        pl[0][pb] = *reinterpret_cast<const frag*>(smem + rowa[0][pb] + 64);
+    }
+    int opaque = 0;
+    // one chunk = 18 stages; LAST: the layer's final chunk (no look-ahead beyond it, the ring runs empty)
+    auto chunk = [&](int ch, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        asm volatile("" : "+v"(opaque));  // keeps `rowa + buffer base` from being hoisted for both parities (36 VGPRs)
+        const int bufbase = (ch & 1) * SP_ABUF + opaque;
+        const int nextbase = ((ch + 1) & 1) * SP_ABUF + opaque;
+        const int s0 = ch * 18;
+#pragma unroll
+        for (int j = 0; j < 18; j++) {
+            if (j == 17) {
+                // this wave has read all of chunk ch (stage 17's fragments came in during stage 16); behind the barrier chunk
+                // ch + 1 is in the other buffer
+                STAMP_ACC_BEGIN;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                STAMP_ACC_END(4);
+            }
+            const int cur = j & 1, nxt = cur ^ 1;
+            // one stage of look-ahead on the pixel fragments; a chunk's last stage reads the next chunk's first
+            if (j + 1 < 18 || !LAST) {
+                const int t = j + 1 < 18 ? (j + 1) >> 1 : 0, k = j + 1 < 18 ? (j + 1) & 1 : 0;
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) {
+                    const int a = rowa[t][pb] + (j + 1 < 18 ? bufbase : nextbase) + k * 32;
+                    ph[nxt][pb] = *reinterpret_cast<const frag*>(smem + a);
+                    pl[nxt][pb] = *reinterpret_cast<const frag*>(smem + a + 64);
+                }
+            }
+            // the D - 1 younger stages stay in flight; the layer's last D stages are not refilled and count down instead
+            const bool tail = LAST && j >= 18 - D;
+            wait_stage(ring[j % D], tail ? CB * 2 * (17 - j) : CB * 2 * (D - 1));
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                const frag wh = __builtin_bit_cast(frag, ring[j % D][cb * 2]);
+                const frag wl = __builtin_bit_cast(frag, ring[j % D][cb * 2 + 1]);
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) {
+                    Mfma<T>::mac(wl, ph[cur][pb], acc[cb][pb]);
+                    Mfma<T>::mac(wh, pl[cur][pb], acc[cb][pb]);
+                    Mfma<T>::mac(wh, ph[cur][pb], acc[cb][pb]);
+                }
+            }
+            if (!tail) load_stage(ring[j % D], wblk + (size_t)(s0 + j + D) * SW_STAGE);  // D stages ahead
+        }
+    };
+    for (int ch = 0; ch + 1 < nch; ch++) chunk(ch, std::false_type{});
+    chunk(nch - 1, std::true_type{});
+
+    // ---- epilogue: as conv3x3_split_kernel (the last chunk's barrier has every wave out of the buffers); the skip values
+    // come from LDS ----
+    STAMP(2);
+    {
+        // all skip values of the lane at once (the ring's registers are free now): one LDS latency instead of one per trip
+        T resv[EIT][16];
+        if (HAS_RES) {
+#pragma unroll
+            for (int i = 0; i < EIT; i++) {
+                const char* sk = smem + SW_LDS_SKIP + (wave * 64 + i * RPT + prow) * SKIP_ROW + ((cg * 8) >> 5) * 128 + ((cg * 8) & 31) * 2;
+                reinterpret_cast<f32x4*>(resv[i])[0] = *reinterpret_cast<const f32x4*>(sk);
+                reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(sk + 64);
+            }
+        }
+        const size_t wrow0 = (size_t)row0 + wave * 64;
+        const int tile0 = wave * 64 * SP;  // the wave's 64 rows of buffer 0 (9,216 B); the same rows of buffer 1 behind
+        auto stage_row = [&](int px) { return CB == 2 ? tile0 + (px >> 5) * SP_ABUF + (px & 31) * 256 : tile0 + px * 128; };
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i];
+                    const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
+                    *reinterpret_cast<f32x4*>(smem + stage_row(pb * 32 + r) + slot * 16) = v;
+                }
+#pragma unroll
+        for (int i = 0; i < EIT; i++) {
+            const int px = i * RPT + prow;
+            const char* rowp = smem + stage_row(px);
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (px & 7)) << 4));
+            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (px & 7)) << 4));
+            float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = v[j] * ds8[j >> 2][j & 3] + bias8[j >> 2][j & 3];
+            if (HAS_RES) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = v[j] + ((float)resv[i][j] + (float)resv[i][8 + j]);  // hi + lo is exact in f32
+            }
+            const bool valid = pslot0 + px < S * S;
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                y[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                if (!valid) y[j] = 0.0f;
+            }
+            if (flags & CONV_OUT_F32) {
+                float* of = reinterpret_cast<float*>(out) + (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y), reinterpret_cast<f32x4*>(of));
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y + 4), reinterpret_cast<f32x4*>(of) + 1);
+            } else {
+                const size_t off = (wrow0 + px) * orow + ocol;
+                T hi[8], lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float yc = y[j] < 65504.0f ? y[j] : 65504.0f;
+                    hi[j] = (T)yc;
+                    lo[j] = (T)(yc - (float)hi[j]);
+                }
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(hi), reinterpret_cast<f32x4*>(out + off));
+                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(lo), reinterpret_cast<f32x4*>(out + off + 32));
+            }
+        }
+    }
+    STAMP(3);
+    STAMP_RT(6);
+    STAMP_FLUSH(wave);
+}
+
 // Every conv variant that exists, with its opt-in for > 64 KiB of dynamic LDS (a per-device function attribute).
 // Called once per device from cattus_hip_create (under its lock), so that no launch ever races the attribute call.
 template <typename T>
@@ -1022,6 +1402,20 @@ static hipError_t split_attrs() {
     CATTUS_ATTR_CB(1)
     CATTUS_ATTR_CB(2)
 #undef CATTUS_ATTR_CB
+    auto setw = [&](const void* fn, int cb) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, sw_lds_total(cb));
+        if (e != hipSuccess && err == hipSuccess) err = e;
+    };
+#define CATTUS_ATTR_CB(CBV)                                                                        \
+    setw(reinterpret_cast<const void*>(&conv3x3_splitw_kernel<false, false, false, CBV>), CBV);    \
+    setw(reinterpret_cast<const void*>(&conv3x3_splitw_kernel<true, false, false, CBV>), CBV);     \
+    setw(reinterpret_cast<const void*>(&conv3x3_splitw_kernel<false, true, false, CBV>), CBV);     \
+    setw(reinterpret_cast<const void*>(&conv3x3_splitw_kernel<true, true, false, CBV>), CBV);      \
+    setw(reinterpret_cast<const void*>(&conv3x3_splitw_kernel<false, false, true, CBV>), CBV);     \
+    setw(reinterpret_cast<const void*>(&conv3x3_splitw_kernel<false, true, true, CBV>), CBV);
+    CATTUS_ATTR_CB(1)
+    CATTUS_ATTR_CB(2)
+#undef CATTUS_ATTR_CB
     return err;
 }
 
@@ -1036,9 +1430,17 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
     const dim3 grid(full_grid * (cb == 1 ? 2 : 1));
     if (act == Act::F16S) {
         typedef _Float16 H;
-#define CATTUS_LAUNCH_SPLIT(R, BIG, STEMV, CBV, SPV)                                                                          \
-    hipExtLaunchKernelGGL((conv3x3_split_kernel<R, BIG, STEMV, CBV>), grid, dim3(512), SP_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                          (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S, flags, SPV)
+        const bool wfrag = (flags & CONV_W_FRAG) != 0;  // `w` is in fragment order: the register-ring kernel
+#define CATTUS_LAUNCH_SPLIT(R, BIG, STEMV, CBV, SPV)                                                                                   \
+    do {                                                                                                                               \
+        if (wfrag)                                                                                                                     \
+            hipExtLaunchKernelGGL((conv3x3_splitw_kernel<R, BIG, STEMV, CBV>), grid, dim3(512), sw_lds_total(CBV), st, ev_start,       \
+                                  ev_stop, 0, (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S,   \
+                                  flags, SPV);                                                                                         \
+        else                                                                                                                           \
+            hipExtLaunchKernelGGL((conv3x3_split_kernel<R, BIG, STEMV, CBV>), grid, dim3(512), SP_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                                  (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S, flags, SPV);   \
+    } while (0)
 #define CATTUS_LAUNCH_SPLIT_CB(CBV)                                                                       \
     do {                                                                                                  \
         if (stem) {                                                                                       \

@@ -141,6 +141,33 @@ def test_f16x2_tracks_the_f32_tower_on_every_shape(game, desc, words, n):
     assert (sub_p == got_p[k : 2 * k + 1]).all() and (sub_v == got_v[k : 2 * k + 1]).all()
 
 
+@pytest.mark.parametrize("game,desc,words,n", [
+    ("chess", dict(**CHESS, blocks=3, filters=256, vhc=8, phc=8), 1, 256),          # the headline layer shape, full grid
+    ("chess", dict(**CHESS, blocks=2, filters=128, vhc=8, phc=8), 1, 61),           # small grid: the 32-cout tile
+    ("hex7", dict(**hex_game(7), blocks=3, filters=64, vhc=16, phc=16), 2, 1100),   # two chunks per layer: the shortest loop
+    ("hex11", dict(**hex_game(11), blocks=2, filters=96, vhc=4, phc=4), 2, 37),     # 128-slot boards, padded filters
+    ("chess", dict(**CHESS, blocks=0, filters=64, vhc=8, phc=8), 1, 5),             # stem only (one chunk)
+])
+def test_f16x2_weight_paths_agree_bit_for_bit(game, desc, words, n, monkeypatch):
+    """The two split-conv kernels -- weights in a register ring fed from L2 (the default), weights through the LDS ring
+    (CATTUS_SPLIT_W=0) -- issue the same MFMA sequence per accumulator: their towers agree bit for bit."""
+    d = NetDesc(**desc)
+    blob = seeded_blob(d, 23)
+    rng = np.random.default_rng(8)
+    hw = d.board * d.board
+    planes = np.zeros((n, d.planes, words), dtype=np.uint64)
+    bits = rng.integers(0, 2, size=(n, d.planes, hw), dtype=np.uint64)
+    for i in range(hw):
+        planes[:, :, i >> 6] |= bits[:, :, i] << np.uint64(i & 63)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CATTUS_SPLIT_W", mode)  # read by cattus_hip_create
+        with HipEvaluator(blob, batch_size=n + 1, plane_words=words, dtype="f16x2") as ev:
+            out[mode] = ev.eval(planes)
+    assert (out["1"][0] == out["0"][0]).all() and (out["1"][1] == out["0"][1]).all()
+    assert np.isfinite(out["1"][0]).all() and np.abs(out["1"][0]).max() > 0
+
+
 def test_f16x2_range_large_batchnorm_scales():
     """f16 holds 65504 at most.  Weights are safe whatever their size (each output channel is pre-scaled by a power of two
     and un-scaled exactly in the epilogue); activations are stored as they are.  A stem BatchNorm weight of 200 puts
