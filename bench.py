@@ -372,6 +372,11 @@ def reduce_leg(leg, torch, dev, world):
 
 
 def main():
+    # stdout carries exactly ONE line, the result JSON: native libraries write to file descriptor 1 too (RCCL prints a
+    # version banner when its first communicator comes up), so everything else this process prints goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -512,7 +517,7 @@ def main():
             assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
         ev.close()
         return dict(elapsed=elapsed, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2,
-                    kernel="tower64_lds_kernel" if launches == 1 else "conv3x3_split_kernel" if dtype == "f16x2" else "conv3x3_mfma_v2_kernel",
+                    kernel="tower64_lds_kernel" if launches == 1 else "conv3x3_splitw_kernel" if dtype == "f16x2" else "conv3x3_mfma_v2_kernel",
                     settle_steps=settle_steps, settle_ms=settle_ms)
 
     def roofline(dtype, r):
@@ -671,7 +676,8 @@ def main():
             out["selfplay"], out["selfplay_full_games"], out["selfplay_config4"] = sp_out, sp_full, sp_c4
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, planes)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if want_pg:
         dist.destroy_process_group()

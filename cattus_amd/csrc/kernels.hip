@@ -1329,23 +1329,23 @@ __global__ void __launch_bounds__(512, 2)
             const f32x4 lo4 = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg) ^ (px & 7)) << 4));
             const f32x4 hi4 = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (px & 7)) << 4));
             float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            // the inverse scale is a power of two, so the product is exact and one fused multiply-add rounds exactly as the
+            // multiply followed by the add of conv3x3_split_kernel does
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = v[j] * ds8[j >> 2][j & 3] + bias8[j >> 2][j & 3];
+            for (int j = 0; j < 8; j++) v[j] = __builtin_fmaf(v[j], ds8[j >> 2][j & 3], bias8[j >> 2][j & 3]);
             if (HAS_RES) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = v[j] + ((float)resv[i][j] + (float)resv[i][8 + j]);  // hi + lo is exact in f32
             }
-            const bool valid = pslot0 + px < S * S;
+            const bool valid = pslot0 + px < S * S;  // slots past the board stay zero: masked once, on the packed vectors
             float y[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                y[j] = v[j] > 0.0f ? v[j] : 0.0f;
-                if (!valid) y[j] = 0.0f;
-            }
+            for (int j = 0; j < 8; j++) y[j] = v[j] > 0.0f ? v[j] : 0.0f;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             if (flags & CONV_OUT_F32) {
                 float* of = reinterpret_cast<float*>(out) + (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
-                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y), reinterpret_cast<f32x4*>(of));
-                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y + 4), reinterpret_cast<f32x4*>(of) + 1);
+                __builtin_nontemporal_store(valid ? *reinterpret_cast<f32x4*>(y) : zero4, reinterpret_cast<f32x4*>(of));
+                __builtin_nontemporal_store(valid ? *reinterpret_cast<f32x4*>(y + 4) : zero4, reinterpret_cast<f32x4*>(of) + 1);
             } else {
                 const size_t off = (wrow0 + px) * orow + ocol;
                 T hi[8], lo[8];
@@ -1355,8 +1355,8 @@ __global__ void __launch_bounds__(512, 2)
                     hi[j] = (T)yc;
                     lo[j] = (T)(yc - (float)hi[j]);
                 }
-                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(hi), reinterpret_cast<f32x4*>(out + off));
-                __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(lo), reinterpret_cast<f32x4*>(out + off + 32));
+                __builtin_nontemporal_store(valid ? *reinterpret_cast<f32x4*>(hi) : zero4, reinterpret_cast<f32x4*>(out + off));
+                __builtin_nontemporal_store(valid ? *reinterpret_cast<f32x4*>(lo) : zero4, reinterpret_cast<f32x4*>(out + off + 32));
             }
         }
     }

@@ -17,7 +17,7 @@ out = sys.argv[1]
 d = json.loads(open(out + "/bench_evaluator_only.json").read().strip().splitlines()[-1])
 tot = calls = 0
 for row in csv.DictReader(open(out + "/kernel_stats.csv")):
-    if "conv3x3_split_kernel" in row["Name"] or "conv3x3_mfma_v2_kernel" in row["Name"]:
+    if "conv3x3_split" in row["Name"] or "conv3x3_mfma_v2_kernel" in row["Name"]:
         tot += int(row["TotalDurationNs"]); calls += int(row["Calls"])
 print(f"value {d['value']:.0f} ms/step {d['ms_per_step']:.4f} launch_us(events) {d['roofline']['avg_launch_us']:.2f} frac {d['roofline']['frac']:.4f} "
       f"two-lane {d['two_batches_in_flight']['value']:.0f} | rocprof conv avg {tot / max(calls, 1) / 1e3:.2f} us over {calls} calls")

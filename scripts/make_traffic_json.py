@@ -39,7 +39,7 @@ def base_name(k: str) -> str:
     return k.replace("void ", "").replace("cattus::", "").split("<")[0].split("(")[0].strip()
 
 
-TOWER = {"f16x2": "conv3x3_split_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
+TOWER = {"f16x2": "conv3x3_splitw_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
 for dtype in ("f16x2", "bf16", "f32"):
     f = tag / f"pmc_summary_{dtype}.json"
     if not f.exists():
