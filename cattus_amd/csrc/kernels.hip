@@ -3,8 +3,10 @@
 //   K0  planes_to_tensor_nchw[64] / pack_planes_nhwc    bitboards -> tensors (HBM-bound); inside the forward pass the
 //                                                       planes are expanded straight into LDS by K1 / K1r instead
 //   K1  conv3x3_mfma_v2<T, HAS_RES, BIG, STEM>          3x3 conv + folded BN (+skip) + ReLU, one launch per layer (MFMA-bound), bf16 / f32
-//   K1s conv3x3_split<HAS_RES, BIG, STEM, CB>           the same layer of the split-precision tower (dtype f16x2, the default):
-//                                                       operands as pairs of f16 values, three f16 MFMA terms per product
+//   K1s conv3x3_splitw<HAS_RES, BIG, STEM, CB>          the same layer of the split-precision tower (dtype f16x2, the default):
+//                                                       operands as pairs of f16 values, three f16 MFMA terms per product;
+//                                                       weights from L2 into a register ring, activations through LDS
+//       conv3x3_split<HAS_RES, BIG, STEM, CB>           its first form, both operands through LDS (CATTUS_SPLIT_W=0; bit-identical)
 //   K1r tower64_lds<CH, BIG>                            whole tower of a <= 64-filter bf16 network in one launch, activations in LDS
 //   K1g conv3x3_generic                                 same arithmetic, any shape, SIMT f32 (checker; wide heads)
 //   K3  head_conv, K4 + K5 head_fc_pair                 1x1 head convs; value FC1 + FC2 + tanh and policy FC (MFMA)
