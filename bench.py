@@ -257,8 +257,12 @@ TRAFFIC_FILE = "profiles/r03_pmc_hbm_traffic.json"
 
 
 def kernels_sha256() -> str:
-    """Identity of the kernel source the traffic counters were collected on."""
-    return hashlib.sha256((ROOT / "cattus_amd" / "csrc" / "kernels.hip").read_bytes()).hexdigest()
+    """Identity of the kernel CODE the traffic counters were collected on: sha256 of kernels.hip with its `//` comments and
+    all white space removed (an edited comment does not make a measurement stale; the file has no block comments and no
+    `//` inside a string literal)."""
+    text = (ROOT / "cattus_amd" / "csrc" / "kernels.hip").read_text()
+    code = "".join("".join(line.split("//", 1)[0].split()) for line in text.splitlines())
+    return hashlib.sha256(code.encode()).hexdigest()
 
 
 def measured_traffic(kernel: str, dtype: str = "f16x2"):

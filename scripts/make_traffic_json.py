@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/rNN_pmc_hbm_traffic.json from the per-dtype PMC summaries of scripts/collect_profiles.sh:
     python scripts/make_traffic_json.py gpurun_out/TAG > profiles/r03_pmc_hbm_traffic.json
-The file carries the sha256 of cattus_amd/csrc/kernels.hip the passes ran on; bench.py withholds the traffic figure
+The file carries the sha256 of the code of cattus_amd/csrc/kernels.hip (comments and white space removed) the passes ran on; bench.py withholds the traffic figure
 when the kernels have changed since (it cannot collect PMC counters inside its own process)."""
 import hashlib
 import json
@@ -10,6 +10,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
 tag = Path(sys.argv[1])
 # algorithmic HBM-side bytes per launch, chess 20x256 at batch 256, averaged over the 41 launches of a step: per launch the
 # 16384 x 256 activations in and out (+ the skip rows in 20 of them) at the dtype's bytes per channel, the layer's weights once
@@ -24,7 +26,7 @@ out = {
               "--warmup 2 --lanes 1 --settle-seconds 0 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32 --no-bf16, MI355X",
     "units": "FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read, so fetched bytes = "
              "2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section). Fabric-side L2 requests: Infinity Cache hits are included.",
-    "kernels_sha256": hashlib.sha256((ROOT / "cattus_amd" / "csrc" / "kernels.hip").read_bytes()).hexdigest(),
+    "kernels_sha256": bench.kernels_sha256(),  # of the code: comments and white space removed
     "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
     "by_dtype": {},
 }
