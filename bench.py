@@ -392,6 +392,7 @@ def main():
     ap.add_argument("--dtype", choices=["f16x2", "bf16", "f32"], default="f16x2", help="tower of the headline `value` (default: the split-precision tower)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="chess20x256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-smi", action="store_true", help="do not sample the device's clock / power under load beside the roofline")
     ap.add_argument("--lanes", type=int, choices=[1, 2], default=2,
                     help="2 = also time the K steps with two batches in flight (extra object; `value` stays single-stream)")
     ap.add_argument("--selfplay-seconds", type=float, default=40.0, help="time budget of the 800-sim self-play leg (0 = skip all self-play legs)")
@@ -459,30 +460,37 @@ def main():
         return x
 
     def under_load_clock_and_power(step):
-        """(sclk MHz, socket power W) as rocm-smi reports them while `step` keeps the GPU busy; None where it cannot."""
+        """(sclk MHz, socket power W) while `step` keeps the GPU busy, read from the amdgpu driver's sysfs files of this rank's
+        device (what rocm-smi prints; plain file reads: no child process); None where the files are missing."""
+        import glob
         import re
-        import shutil
-        import subprocess
+        import statistics
 
-        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-        if not os.path.exists(exe):
-            return None
+        from cattus_amd.affinity import torch_pci_bus_ids
+
         try:
+            ids = torch_pci_bus_ids(local_rank + 1)
+            base = f"/sys/bus/pci/devices/{ids[local_rank]}" if ids else None
+            if not base or not os.path.exists(base + "/pp_dpm_sclk"):
+                return None
+            power_files = glob.glob(base + "/hwmon/hwmon*/power1_average") + glob.glob(base + "/hwmon/hwmon*/power1_input")
+            sclk, power = [], []
             for _ in range(100):
                 step()
-            p = subprocess.Popen([exe, "-d", str(local_rank), "--showclocks", "--showpower"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
             t0 = time.perf_counter()
-            while p.poll() is None and time.perf_counter() - t0 < 20:
+            while time.perf_counter() - t0 < 1.5:
                 for _ in range(20):
                     step()
+                m = re.search(r"(\d+)Mhz\s*\*", open(base + "/pp_dpm_sclk").read())
+                if m:
+                    sclk.append(int(m.group(1)))
+                if power_files:
+                    power.append(int(open(power_files[0]).read()) / 1e6)
                 torch.cuda.synchronize()
-            text = p.communicate(timeout=5)[0]
-            torch.cuda.synchronize()
-            sclk = re.search(r"sclk clock level:\s*\d+:?\s*\((\d+)Mhz\)", text)
-            power = re.search(r"Power \(W\):\s*([0-9.]+)", text)
             if not sclk:
                 return None
-            return dict(sclk_mhz=int(sclk.group(1)), socket_power_w=float(power.group(1)) if power else None)
+            return dict(sclk_mhz=int(statistics.median(sclk)), socket_power_w=round(statistics.median(power), 1) if power else None,
+                        samples=len(sclk))
         except Exception:  # noqa: BLE001 - a diagnostic; the measurement does not depend on it
             return None
 
@@ -526,9 +534,9 @@ def main():
         # roofline of the dominant kernel (3x3 conv tower launch): event-stamped launch durations of the same
         # forward, taken right behind the timed region so that the device is in the same state as for `value`
         launch_us, launches = ev.time_tower(batch, 20 if dtype != "f32" else 5) if rank == 0 else (0.0, 1)
-        # clock and power while the same steps keep running (rocm-smi on rank 0, best effort): the 2.5 PF peak is a
+        # clock and power while the same steps keep running (sysfs, rank 0, best effort): the 2.5 PF peak is a
         # 2.4 GHz figure, and under its MFMA kernels the part holds less
-        smi = under_load_clock_and_power(step) if rank == 0 and world == 1 else None
+        smi = under_load_clock_and_power(step) if rank == 0 and not args.no_smi else None
         elapsed2 = None
         if lanes == 2:
             # the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
@@ -574,7 +582,7 @@ def main():
             # the peak above is clock 2.4 GHz x 1,024 SIMDs x FLOP per cycle: scaled to the clock the part holds under this
             # kernel it says what share of the ELAPSED matrix-pipe cycles the kernel fills
             scale = smi["sclk_mhz"] / 2400.0
-            under_load = dict(smi, source="rocm-smi --showclocks --showpower while the same steps run (untimed)",
+            under_load = dict(smi, source="amdgpu sysfs (pp_dpm_sclk, hwmon power1_average) of this device while the same steps run (untimed); what rocm-smi prints",
                               peak_at_this_clock=peak * scale, mfma_pipe_frac_at_this_clock=MFMA_TERMS[dtype] * achieved / (peak * scale))
         return {
             "kernel": r["kernel"],
