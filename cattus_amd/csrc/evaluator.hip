@@ -862,6 +862,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     }
     const char* wait_mode = getenv("CATTUS_HIP_WAIT");
     set_conv_cb(getenv("CATTUS_CONV_CB") ? atoi(getenv("CATTUS_CONV_CB")) : 0);
+    set_conv_pbw(getenv("CATTUS_CONV_PBW") ? atoi(getenv("CATTUS_CONV_PBW")) : 0);
     const char* fused_stem_env = getenv("CATTUS_FUSED_STEM");
     const char* t64_ch_env = getenv("CATTUS_T64_CH");
     const char* t64_ls_env = getenv("CATTUS_T64_LS");

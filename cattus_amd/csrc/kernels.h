@@ -63,6 +63,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 
 // Forces the conv kernel's tile (1: 256 rows x 32 couts, 2: 256 rows x 64 couts; 0: chosen by grid size).
 void set_conv_cb(int v);
+// 2: the f16x2 conv never uses its 128-row workgroup (otherwise chosen for grids of <= 128 32-cout workgroups).
+void set_conv_pbw(int v);
 
 // ---- K1 resident: whole tower of a network with <= 64 (padded) filters in one launch, bf16 (see kernels.hip) ----
 struct Tower64Layer {

@@ -628,6 +628,8 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 
 int g_conv_cb = 0;  // 0: by grid size; 1 / 2: 32 / 64 couts per workgroup (CATTUS_CONV_CB, A/B runs and the equality test)
 void set_conv_cb(int v) { g_conv_cb = (v == 1 || v == 2) ? v : 0; }
+static std::atomic<int> g_conv_pbw{0};  // 2: never / 1: whenever the tile is 32 couts -- the 128-row workgroup of the f16x2 conv (A/B, tests)
+void set_conv_pbw(int v) { g_conv_pbw = (v == 1 || v == 2) ? v : 0; }
 
 
 // ------------------------------------------------------------------------------------------
@@ -1012,10 +1014,13 @@ __global__ void __launch_bounds__(512, 2)
 constexpr int SW_D = 6;                       // weight stages in flight per consumer wave; divides the 18 stages of a chunk
 constexpr int SW_STAGE = 2048;                // bytes per 32-cout block and stage: hi fragment, lo fragment
 constexpr int SW_LDS_SKIP = 2 * SP_ABUF;      // skip rows behind the two activation buffers
-constexpr int sw_lds_total(int cb) { return SW_LDS_SKIP + 256 * 32 * cb * 4; }  // 139,552 B at CB = 2
+constexpr int sw_lds_total(int cb, int pbw = 2) { return 2 * (128 * pbw * SP + SP) + 128 * pbw * 32 * cb * 4; }  // 139,552 B at CB = 2
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <bool HAS_RES, bool BIG, bool STEM, int CB>
+// PBW: 32-pixel blocks per consumer wave.  2: the workgroup covers 256 tower rows (64 pixels per wave); 1 (with CB = 1, for
+// grids that would otherwise leave CUs empty: <= 64 leaves of an 8x8 game at 256 filters): 128 rows, 32 pixels per wave -- twice
+// the workgroups, half the MFMA chain per wave.
+template <bool HAS_RES, bool BIG, bool STEM, int CB, int PBW = 2>
 __global__ void __launch_bounds__(512, 2)
     conv3x3_splitw_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wf, const float* __restrict__ bias,
                           const _Float16* __restrict__ res, _Float16* __restrict__ out, int cin, int cout, int S, int flags,
@@ -1025,8 +1030,15 @@ __global__ void __launch_bounds__(512, 2)
     constexpr int KC = 32;        // channels (pairs) per 128-byte chunk
     constexpr int CPW = 32 * CB;  // output channels of this workgroup
     constexpr int D = SW_D;
+    static_assert(PBW == 2 || (PBW == 1 && CB == 1), "the 128-row workgroup exists for the 32-cout tile only");
+    constexpr int RW = 128 * PBW;       // tower rows of this workgroup
+    constexpr int PXW = 32 * PBW;       // pixels (rows) per consumer wave
+    constexpr int ZERO = RW * SP;       // a buffer's zero row, behind its RW rows
+    constexpr int ABUF = ZERO + SP;     // bytes of an activation buffer
+    constexpr int SKIP0 = 2 * ABUF;     // skip rows behind the two buffers
     constexpr int SKIP_ROW = CPW * 4;   // bytes of a skip row: [32 hi | 32 lo] per 32 couts
-    constexpr int SKIP_PPW = 8 * CB;    // 1 KiB pieces of the skip rows per loader wave
+    constexpr int SKIP_PPW = 4 * CB * PBW;  // 1 KiB pieces of the skip rows per loader wave
+    constexpr int NHALF = PBW;          // an activation chunk is NHALF x 18 pieces of 1 KiB
     static_assert(18 % D == 0, "a chunk's 18 stages must map onto whole turns of the ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1042,9 +1054,9 @@ __global__ void __launch_bounds__(512, 2)
     int logical = blockIdx.x;
     if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int cout0 = (logical % ncb) * CPW;
-    const int row0 = (logical / ncb) * ROWS_PER_WG;
+    const int row0 = (logical / ncb) * RW;
 
-    if (tid < 18) reinterpret_cast<f32x4*>(smem + (tid / 9) * SP_ABUF + SP_ZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 18) reinterpret_cast<f32x4*>(smem + (tid / 9) * ABUF + ZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero rows are written before the first barrier
 
     const int nch = cin / KC;
@@ -1057,10 +1069,10 @@ __global__ void __launch_bounds__(512, 2)
         // stage and CU): let them go first
         __builtin_amdgcn_s_setprio(3);
         const int lw = wave - 4;
-        uint32_t off_a[2][SP_APL];
-        int dst_a[2][SP_APL];
+        uint32_t off_a[NHALF][SP_APL];
+        int dst_a[NHALF][SP_APL];
 #pragma unroll
-        for (int g = 0; g < 2; g++)
+        for (int g = 0; g < NHALF; g++)
 #pragma unroll
             for (int i = 0; i < SP_APL; i++) {  // the padded image of a chunk, as in conv3x3_split_kernel
                 const int id = g * 18 + min(lw * SP_APL + i, 17);
@@ -1071,19 +1083,19 @@ __global__ void __launch_bounds__(512, 2)
         const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
         auto issue_chunk = [&](int ch) {  // activation chunk ch -> buffer ch & 1
             const char* src = abase0 + (size_t)ch * 128;
-            char* dst = smem + (ch & 1) * SP_ABUF;
+            char* dst = smem + (ch & 1) * ABUF;
 #pragma unroll
-            for (int g = 0; g < 2; g++)
+            for (int g = 0; g < NHALF; g++)
 #pragma unroll
                 for (int i = 0; i < SP_APL; i++) glds16(src + off_a[g][i], dst + dst_a[g][i]);
         };
         if constexpr (STEM) {
-            // K0 fused (one chunk, no DMA): this thread expands pixel row (lw * 64 + lane) of the workgroup's 256 rows
+            // K0 fused (one chunk, no DMA): this thread expands pixel row (lw * 64 + lane) of the workgroup's RW rows
             constexpr int MAXC = 32;
             const int row = lw * 64 + lane;
             const uint32_t grow = (uint32_t)(row0 + row), slots = BIG ? 128u : 64u;
             const uint32_t board = grow / slots, px = grow % slots;
-            const bool live = board < sp.n && (int)px < S * S;
+            const bool live = row < RW && board < sp.n && (int)px < S * S;
             typedef const __attribute__((address_space(1))) uint64_t* gu64p;
             const gu64p pl = (gu64p)(sp.planes + (size_t)(live ? board : 0) * sp.C * sp.w64 + (live ? (px >> 6) : 0));
             uint64_t words[MAXC];
@@ -1098,7 +1110,7 @@ __global__ void __launch_bounds__(512, 2)
                     const int c = sl * 8 + i;
                     vals[i] = (c < MAXC && ((words[c < MAXC ? c : 0] >> (px & 63)) & 1ull)) ? (T)1.0f : (T)0.0f;
                 }
-                *reinterpret_cast<f32x4*>(dstrow + sl * 16) = *reinterpret_cast<f32x4*>(vals);
+                if (row < RW) *reinterpret_cast<f32x4*>(dstrow + sl * 16) = *reinterpret_cast<f32x4*>(vals);
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // P
         } else {
@@ -1113,7 +1125,7 @@ __global__ void __launch_bounds__(512, 2)
                 for (int i = 0; i < SKIP_PPW; i++) {
                     const int pc = lw * SKIP_PPW + i;
                     const int q = pc * 1024 + lane * 16, row = q / SKIP_ROW, col = q % SKIP_ROW;
-                    glds16(rbase + (size_t)row * cout * 4 + col, smem + SW_LDS_SKIP + pc * 1024);
+                    glds16(rbase + (size_t)row * cout * 4 + col, smem + SKIP0 + pc * 1024);
                 }
             }
         }
@@ -1195,7 +1207,7 @@ __global__ void __launch_bounds__(512, 2)
 
     const int r = lane & 31, h = lane >> 5;
     // epilogue operands first (ordinary loads, older than every ring load: the hand-counted waits below stay exact)
-    constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = 64 / RPT;
+    constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = PXW / RPT;
     const int prow = lane / LPR, cg = lane % LPR;
     f32x4 bias8[2], ds8[2];
 #pragma unroll
@@ -1207,11 +1219,12 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
     for (int d = 0; d < D; d++) load_stage(ring[d], wblk + (size_t)d * SW_STAGE);
 
-    const int pslot0 = BIG ? (wave & 1) * 64 : 0;
-    const int board_row = BIG ? (wave >> 1) * 128 : wave * 64;  // first LDS row of this wave's board
-    int rowa[9][2];
+    constexpr int SLOTS = BIG ? 128 : 64, WPB = SLOTS / PXW;  // consumer waves per board
+    const int pslot0 = (wave % WPB) * PXW;           // this wave's first pixel slot of its board
+    const int board_row = (wave / WPB) * SLOTS;      // first LDS row of this wave's board
+    int rowa[9][PBW];
 #pragma unroll
-    for (int pb = 0; pb < 2; pb++) {
+    for (int pb = 0; pb < PBW; pb++) {
         const int p = pslot0 + pb * 32 + r;
         const int ph_ = p / S, pw = p - ph_ * S;
         const bool pvalid = p < S * S;
@@ -1219,15 +1232,15 @@ __global__ void __launch_bounds__(512, 2)
         for (int t9 = 0; t9 < 9; t9++) {
             const int hh = ph_ + t9 / 3 - 1, ww = pw + t9 % 3 - 1;
             const bool ok = pvalid && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
-            rowa[t9][pb] = (ok ? (board_row + hh * S + ww) * SP : SP_ZERO) + h * 16;
+            rowa[t9][pb] = (ok ? (board_row + hh * S + ww) * SP : ZERO) + h * 16;
         }
     }
 
-    f32x16 acc[CB][2];
+    f32x16 acc[CB][PBW];
 #pragma unroll
     for (int i = 0; i < CB; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < PBW; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
@@ -1241,9 +1254,9 @@ __global__ void __launch_bounds__(512, 2)
     }
     STAMP(1);
     // pixel fragments: [stage parity][pixel block]
-    frag ph[2][2], pl[2][2];
+    frag ph[2][PBW], pl[2][PBW];
 #pragma unroll
-    for (int pb = 0; pb < 2; pb++) {
+    for (int pb = 0; pb < PBW; pb++) {
         ph[0][pb] = *reinterpret_cast<const frag*>(smem + rowa[0][pb]);
         pl[0][pb] = *reinterpret_cast<const frag*>(smem + rowa[0][pb] + 64);
     }
@@ -1252,8 +1265,8 @@ __global__ void __launch_bounds__(512, 2)
     auto chunk = [&](int ch, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         asm volatile("" : "+v"(opaque));  // keeps `rowa + buffer base` from being hoisted for both parities (36 VGPRs)
-        const int bufbase = (ch & 1) * SP_ABUF + opaque;
-        const int nextbase = ((ch + 1) & 1) * SP_ABUF + opaque;
+        const int bufbase = (ch & 1) * ABUF + opaque;
+        const int nextbase = ((ch + 1) & 1) * ABUF + opaque;
         const int s0 = ch * 18;
 #pragma unroll
         for (int j = 0; j < 18; j++) {
@@ -1269,7 +1282,7 @@ __global__ void __launch_bounds__(512, 2)
             if (j + 1 < 18 || !LAST) {
                 const int t = j + 1 < 18 ? (j + 1) >> 1 : 0, k = j + 1 < 18 ? (j + 1) & 1 : 0;
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) {
+                for (int pb = 0; pb < PBW; pb++) {
                     const int a = rowa[t][pb] + (j + 1 < 18 ? bufbase : nextbase) + k * 32;
                     ph[nxt][pb] = *reinterpret_cast<const frag*>(smem + a);
                     pl[nxt][pb] = *reinterpret_cast<const frag*>(smem + a + 64);
@@ -1283,7 +1296,7 @@ __global__ void __launch_bounds__(512, 2)
                 const frag wh = __builtin_bit_cast(frag, ring[j % D][cb * 2]);
                 const frag wl = __builtin_bit_cast(frag, ring[j % D][cb * 2 + 1]);
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) {
+                for (int pb = 0; pb < PBW; pb++) {
                     Mfma<T>::mac(wl, ph[cur][pb], acc[cb][pb]);
                     Mfma<T>::mac(wh, pl[cur][pb], acc[cb][pb]);
                     Mfma<T>::mac(wh, ph[cur][pb], acc[cb][pb]);
@@ -1304,18 +1317,18 @@ __global__ void __launch_bounds__(512, 2)
         if (HAS_RES) {
 #pragma unroll
             for (int i = 0; i < EIT; i++) {
-                const char* sk = smem + SW_LDS_SKIP + (wave * 64 + i * RPT + prow) * SKIP_ROW + ((cg * 8) >> 5) * 128 + ((cg * 8) & 31) * 2;
+                const char* sk = smem + SKIP0 + (wave * PXW + i * RPT + prow) * SKIP_ROW + ((cg * 8) >> 5) * 128 + ((cg * 8) & 31) * 2;
                 reinterpret_cast<f32x4*>(resv[i])[0] = *reinterpret_cast<const f32x4*>(sk);
                 reinterpret_cast<f32x4*>(resv[i])[1] = *reinterpret_cast<const f32x4*>(sk + 64);
             }
         }
-        const size_t wrow0 = (size_t)row0 + wave * 64;
-        const int tile0 = wave * 64 * SP;  // the wave's 64 rows of buffer 0 (9,216 B); the same rows of buffer 1 behind
-        auto stage_row = [&](int px) { return CB == 2 ? tile0 + (px >> 5) * SP_ABUF + (px & 31) * 256 : tile0 + px * 128; };
+        const size_t wrow0 = (size_t)row0 + wave * PXW;
+        const int tile0 = wave * PXW * SP;  // the wave's own rows of buffer 0 (PXW x 144 B); the same rows of buffer 1 behind
+        auto stage_row = [&](int px) { return CB == 2 ? tile0 + (px >> 5) * ABUF + (px & 31) * 256 : tile0 + px * 128; };
 #pragma unroll
         for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-            for (int pb = 0; pb < 2; pb++)
+            for (int pb = 0; pb < PBW; pb++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     f32x4 v;
@@ -1434,6 +1447,8 @@ static hipError_t split_attrs() {
     CATTUS_ATTR_CB(1)
     CATTUS_ATTR_CB(2)
 #undef CATTUS_ATTR_CB
+    // the 128-row workgroup needs no opt-in (53,536 B)
+    static_assert(sw_lds_total(1, 1) <= 64 * 1024, "the small tile fits the default dynamic LDS limit");
     return err;
 }
 
@@ -1449,9 +1464,16 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
     if (act == Act::F16S) {
         typedef _Float16 H;
         const bool wfrag = (flags & CONV_W_FRAG) != 0;  // `w` is in fragment order: the register-ring kernel
+        // 128 rows x 32 couts per workgroup while even the 32-cout grid would leave half of the CUs empty (register ring only)
+        const bool half_rows = wfrag && cb == 1 && ((grid.x <= 128 && g_conv_pbw != 2) || g_conv_pbw == 1);
+        const dim3 grid_half(grid.x * 2);
 #define CATTUS_LAUNCH_SPLIT(R, BIG, STEMV, CBV, SPV)                                                                                   \
     do {                                                                                                                               \
-        if (wfrag)                                                                                                                     \
+        if (wfrag && half_rows && CBV == 1)                                                                                            \
+            hipExtLaunchKernelGGL((conv3x3_splitw_kernel<R, BIG, STEMV, 1, 1>), grid_half, dim3(512), sw_lds_total(1, 1), st, ev_start, \
+                                  ev_stop, 0, (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S,   \
+                                  flags, SPV);                                                                                         \
+        else if (wfrag)                                                                                                                \
             hipExtLaunchKernelGGL((conv3x3_splitw_kernel<R, BIG, STEMV, CBV>), grid, dim3(512), sw_lds_total(CBV), st, ev_start,       \
                                   ev_stop, 0, (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S,   \
                                   flags, SPV);                                                                                         \

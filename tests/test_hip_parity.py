@@ -143,9 +143,11 @@ def test_f16x2_tracks_the_f32_tower_on_every_shape(game, desc, words, n):
 
 @pytest.mark.parametrize("game,desc,words,n", [
     ("chess", dict(**CHESS, blocks=3, filters=256, vhc=8, phc=8), 1, 256),          # the headline layer shape, full grid
-    ("chess", dict(**CHESS, blocks=2, filters=128, vhc=8, phc=8), 1, 61),           # small grid: the 32-cout tile
+    ("chess", dict(**CHESS, blocks=2, filters=128, vhc=8, phc=8), 1, 61),           # small grid: 128 rows x 32 couts per workgroup
+    ("chess", dict(**CHESS, blocks=2, filters=256, vhc=8, phc=8), 1, 100),          # 256 rows x 32 couts per workgroup
     ("hex7", dict(**hex_game(7), blocks=3, filters=64, vhc=16, phc=16), 2, 1100),   # two chunks per layer: the shortest loop
-    ("hex11", dict(**hex_game(11), blocks=2, filters=96, vhc=4, phc=4), 2, 37),     # 128-slot boards, padded filters
+    ("hex11", dict(**hex_game(11), blocks=2, filters=96, vhc=4, phc=4), 2, 37),     # 128-slot boards, padded filters, 128-row workgroups
+    ("hex9", dict(**hex_game(9), blocks=2, filters=128, vhc=4, phc=4), 2, 100),     # 128-slot boards, 256-row workgroups
     ("chess", dict(**CHESS, blocks=0, filters=64, vhc=8, phc=8), 1, 5),             # stem only (one chunk)
 ])
 def test_f16x2_weight_paths_agree_bit_for_bit(game, desc, words, n, monkeypatch):
