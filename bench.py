@@ -459,6 +459,15 @@ def main():
             return float(t.item())
         return x
 
+    def gather_over_ranks(x):
+        """x of every rank, in rank order (the GPUs of a node do not hold the same clock under the tower: the job's rate is the
+        slowest one's, and this says which)."""
+        if world > 1:
+            t = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+            dist.all_gather(t, torch.tensor([x], dtype=torch.float64, device=cdev))
+            return [float(v.item()) for v in t]
+        return [x]
+
     def under_load_clock_and_power(step):
         """(sclk MHz, socket power W) while `step` keeps the GPU busy, read from the amdgpu driver's sysfs files of this rank's
         device (what rocm-smi prints; plain file reads: no child process); None where the files are missing."""
@@ -527,8 +536,11 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        torch.cuda.synchronize()  # this rank's own K steps, before it waits for the others at the closing barrier
+        own = time.perf_counter() - t0
         sync_all()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        own_all = gather_over_ranks(own)
         # sanity: the timed kernels produced real numbers
         assert bool(torch.isfinite(d_policy).all()) and bool(torch.isfinite(d_value).all())
         # roofline of the dominant kernel (3x3 conv tower launch): event-stamped launch durations of the same
@@ -563,7 +575,7 @@ def main():
             elapsed2 = max_over_ranks(time.perf_counter() - t0)
             assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
         ev.close()
-        return dict(elapsed=elapsed, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2,
+        return dict(elapsed=elapsed, own_all=own_all, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2,
                     kernel="tower64_lds_kernel" if launches == 1 else "conv3x3_splitw_kernel" if dtype == "f16x2" else "conv3x3_mfma_v2_kernel",
                     settle_steps=settle_steps, settle_ms=settle_ms, smi=smi)
 
@@ -707,6 +719,9 @@ def main():
                 "flop_per_leaf": d.flops_per_position(),
             },
             "per_gpu_value": value / world,
+            # each rank's own rate over its K steps, before the closing barrier (`value` is the job's: K steps of every rank in
+            # the slowest rank's time)
+            "per_rank_value": [batch * args.steps / t for t in main_r["own_all"]],
             "effective_warmup_steps": args.warmup + main_r["settle_steps"],
             "roofline": roofline(args.dtype, main_r),
             "host": {"cpus_of_this_rank": len(cpu_share), "ranks_on_this_node": local_world},
