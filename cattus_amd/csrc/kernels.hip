@@ -23,6 +23,8 @@
 #include <hip/hip_ext.h>
 
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace cattus {
@@ -607,7 +609,16 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             }
             // non-temporal: the line leaves for memory early instead of at the kernel's end (plain stores: launch 18.35 ->
             // 18.7 us, one batch at a time unchanged, two batches in flight +3 %, self-play +0.8 %; profiles/r02_experiments.txt)
-            if (sizeof(T) == 2) {
+            // On the small-grid tile (CB = 1) plain stores: the output stays in the L2 of the XCD whose workgroups read it back as
+            // the next layer's input (measured on the split conv: 18.5 against 19.9 us per launch at 64 leaves).
+            if constexpr (CB == 1) {
+                if (sizeof(T) == 2) {
+                    *reinterpret_cast<f32x4*>(out + off) = *reinterpret_cast<f32x4*>(ov);
+                } else {
+                    reinterpret_cast<f32x4*>(out + off)[0] = reinterpret_cast<f32x4*>(ov)[0];
+                    reinterpret_cast<f32x4*>(out + off)[1] = reinterpret_cast<f32x4*>(ov)[1];
+                }
+            } else if (sizeof(T) == 2) {
                 __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(ov), reinterpret_cast<f32x4*>(out + off));
             } else {
                 __builtin_nontemporal_store(reinterpret_cast<f32x4*>(ov)[0], reinterpret_cast<f32x4*>(out + off));
@@ -1011,6 +1022,11 @@ __global__ void __launch_bounds__(512, 2)
 // arrive only after chunk + 1 has landed, so the last stage's look-ahead reads cross into the next chunk and the fragment
 // pipeline never drains at a barrier.
 // The MFMA sequence per accumulator is that of conv3x3_split_kernel, so the two kernels agree bit for bit.
+//
+// Small grids: with CB = 1 (32 couts per workgroup) the outputs are stored plainly (the next layer finds its input in the
+// XCD's L2), and while even that grid would leave half of the CUs empty the workgroup covers 128 rows instead of 256
+// (PBW = 1: 32 pixels per consumer wave, half the MFMA chain per wave, twice the workgroups): 14.0 us per launch at 64
+// leaves of chess 20x256, 11.9 at 17 (256-row workgroups: 18.6 / 18.4; the LDS-ring kernel: 22.5 / 22.0).
 constexpr int SW_D = 6;                       // weight stages in flight per consumer wave; divides the 18 stages of a chunk
 constexpr int SW_STAGE = 2048;                // bytes per 32-cout block and stage: hi fragment, lo fragment
 constexpr int SW_LDS_SKIP = 2 * SP_ABUF;      // skip rows behind the two activation buffers
@@ -1464,6 +1480,10 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
     if (act == Act::F16S) {
         typedef _Float16 H;
         const bool wfrag = (flags & CONV_W_FRAG) != 0;  // `w` is in fragment order: the register-ring kernel
+        if (wfrag && !stem && cin < 64) {  // its loaders request two chunks up front (kernels.h); the evaluator pads filters to 64
+            fprintf(stderr, "cattus: launch_conv3x3_mfma: CONV_W_FRAG needs cin >= 64 on a non-stem layer (got %u)\n", cin);
+            abort();
+        }
         // 128 rows x 32 couts per workgroup while even the 32-cout grid would leave half of the CUs empty (register ring only)
         const bool half_rows = wfrag && cb == 1 && ((grid.x <= 128 && g_conv_pbw != 2) || g_conv_pbw == 1);
         const dim3 grid_half(grid.x * 2);
