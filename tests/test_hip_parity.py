@@ -322,6 +322,35 @@ def test_half_cout_workgroups_equal_full_ones(game, desc, words, n, dtype, monke
         assert (outs[1][0][:8] == want_p).all() and (outs[1][1][:8] == want_v).all()
 
 
+@pytest.mark.parametrize("game,desc,words,n", [
+    ("chess", dict(**CHESS, blocks=3, filters=256, vhc=8, phc=8), 1, 40),            # 64-slot boards: two waves per board
+    ("hex11", dict(**hex_game(11), blocks=2, filters=128, vhc=16, phc=16), 2, 21),   # 128-slot boards: one board per workgroup
+    ("ttt", dict(planes=3, board=3, moves=9, blocks=2, filters=64, vhc=8, phc=8), 1, 7),
+])
+def test_f16x2_half_row_workgroups_equal_full_ones(game, desc, words, n, monkeypatch):
+    """Batches that would leave half of the CUs empty run the f16x2 conv on 128-row x 32-cout workgroups (32 pixels per
+    consumer wave); CATTUS_CONV_PBW=2 keeps the 256-row ones, =1 forces the small ones wherever the tile is 32 couts: same
+    MFMA sequence per output, same bits."""
+    d = NetDesc(**desc)
+    blob = seeded_blob(d, 29)
+    rng = np.random.default_rng(13)
+    hw = d.board * d.board
+    planes = np.zeros((n, d.planes, words), dtype=np.uint64)
+    bits = rng.integers(0, 2, size=(n, d.planes, hw), dtype=np.uint64)
+    for i in range(hw):
+        planes[:, :, i >> 6] |= bits[:, :, i] << np.uint64(i & 63)
+    outs = []
+    for pbw in ("2", "1", None):
+        if pbw is None:
+            monkeypatch.delenv("CATTUS_CONV_PBW")
+        else:
+            monkeypatch.setenv("CATTUS_CONV_PBW", pbw)
+        with HipEvaluator(blob, batch_size=n, plane_words=words, dtype="f16x2") as ev:
+            outs.append(ev.eval(planes))
+    for o in outs[1:]:
+        assert (o[0] == outs[0][0]).all() and (o[1] == outs[0][1]).all()
+
+
 def test_wide_heads_take_the_generic_path_and_refuse_bf16():
     d = NetDesc(**hex_game(5), blocks=1, filters=32, vhc=24, phc=24)  # 48 head channels > one 32-row MFMA tile
     blob = seeded_blob(d, 4)
