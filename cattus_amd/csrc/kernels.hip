@@ -1029,7 +1029,6 @@ __global__ void __launch_bounds__(512, 2)
 // leaves of chess 20x256, 11.9 at 17 (256-row workgroups: 18.6 / 18.4; the LDS-ring kernel: 22.5 / 22.0).
 constexpr int SW_D = 6;                       // weight stages in flight per consumer wave; divides the 18 stages of a chunk
 constexpr int SW_STAGE = 2048;                // bytes per 32-cout block and stage: hi fragment, lo fragment
-constexpr int SW_LDS_SKIP = 2 * SP_ABUF;      // skip rows behind the two activation buffers
 constexpr int sw_lds_total(int cb, int pbw = 2) { return 2 * (128 * pbw * SP + SP) + 128 * pbw * 32 * cb * 4; }  // 139,552 B at CB = 2
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
