@@ -606,6 +606,9 @@ def main():
             "traffic": traffic,
             "traffic_source": source,
             "avg_launch_us": r["launch_us"],
+            "avg_launch_note": "per-launch start / stop HIP events (hipExtLaunchKernelGGL) on the launches of the same forward, in a pass of "
+                               "its own right behind the timed steps: the stamps cost ~0.5 us per launch, so launches_per_step x avg_launch_us "
+                               "can exceed ms_per_step by 1-2 % -- `achieved` and `frac` are low by that much, never high",
             "launches_per_step": r["launches"],
             "flop_per_launch": flop_per_launch,
             "mfma_terms_per_multiply_add": MFMA_TERMS[dtype],
