@@ -549,6 +549,8 @@ def main():
         # clock and power while the same steps keep running (sysfs, rank 0, best effort): the 2.5 PF peak is a
         # 2.4 GHz figure, and under its MFMA kernels the part holds less
         smi = under_load_clock_and_power(step) if rank == 0 and not args.no_smi else None
+        # what THIS device's matrix pipe sustains on nothing but back-to-back MFMAs of the tower's kind (1 s; rank 0)
+        sustained = ev.mfma_sustained(1.0) if rank == 0 and not args.no_smi else None
         elapsed2 = None
         if lanes == 2:
             # the same K steps with two batches in flight (evaluator lanes 0/1 on two streams), as the self-play
@@ -577,7 +579,7 @@ def main():
         ev.close()
         return dict(elapsed=elapsed, own_all=own_all, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2,
                     kernel="tower64_lds_kernel" if launches == 1 else "conv3x3_splitw_kernel" if dtype == "f16x2" else "conv3x3_mfma_v2_kernel",
-                    settle_steps=settle_steps, settle_ms=settle_ms, smi=smi)
+                    settle_steps=settle_steps, settle_ms=settle_ms, smi=smi, sustained=sustained)
 
     def roofline(dtype, r):
         """Dominant kernel = the tower conv launch.  `achieved` counts ALGORITHMIC flops (2 x multiply-adds of the
@@ -596,6 +598,14 @@ def main():
             scale = smi["sclk_mhz"] / 2400.0
             under_load = dict(smi, source="amdgpu sysfs (pp_dpm_sclk, hwmon power1_average) of this device while the same steps run (untimed); what rocm-smi prints",
                               peak_at_this_clock=peak * scale, mfma_pipe_frac_at_this_clock=MFMA_TERMS[dtype] * achieved / (peak * scale))
+        sustained = None
+        if r.get("sustained"):
+            # the nominal peak is a 2.4 GHz figure; under MFMA load the part's power management sets the clock.  A kernel of
+            # nothing but back-to-back MFMAs of this kind (one wave per SIMD, operands in registers, ~50 us launches for 1 s)
+            # is what the pipe can deliver on THIS device, measured in this run right behind the timed steps
+            sustained = dict(tflops=r["sustained"], frac_of_nominal=r["sustained"] / peak,
+                             mfma_pipe_frac_of_sustained=MFMA_TERMS[dtype] * achieved / r["sustained"],
+                             how="cattus_hip_mfma_sustained: back-to-back MFMAs of the tower's kind on every SIMD, no memory traffic, 1 s")
         return {
             "kernel": r["kernel"],
             "bound": "mfma",
@@ -615,6 +625,7 @@ def main():
             "mfma_pipe_frac": MFMA_TERMS[dtype] * achieved / peak,
             "peak_of": "f16 / bf16 32x32x16 MFMA, dense, at the 2.4 GHz peak clock" if dtype != "f32" else "f32 32x32x2 MFMA, at the 2.4 GHz peak clock",
             "under_load": under_load,
+            "sustained": sustained,
         }
 
     def side_object(dtype, r):

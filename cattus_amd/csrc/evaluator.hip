@@ -1120,6 +1120,44 @@ CATTUS_API int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, 
     return CATTUS_OK;
 }
 
+CATTUS_API int cattus_hip_mfma_sustained(cattus_eval* e, double seconds, double* tflops) {
+    if (!e || !tflops) return fail(CATTUS_E_INVALID, "NULL argument");
+    if (!(seconds > 0) || seconds > 30) return fail(CATTUS_E_INVALID, "seconds out of range");
+    Lane& L = e->lanes[0];
+    std::lock_guard<std::mutex> lk(L.mu);
+    HIP_TRY(hipSetDevice(e->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+    const int cus = prop.multiProcessorCount;
+    DevBuf out;
+    int rc = out.alloc((size_t)cus * 256 * 4);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    // launches of ~50 us (the length of a conv layer), groups of 50, until `seconds` have passed: the last group's rate
+    const int iters = e->act == Act::F32 ? 480 : 640, reps = 50;
+    double rate = 0, elapsed = 0;
+    while (elapsed < seconds) {
+        double flop = 0;
+        (void)hipEventRecord(e0, L.stream);
+        for (int r = 0; r < reps; r++) flop += launch_mfma_sustain(e->act, cus, iters, out.as<float>(), L.stream);
+        (void)hipEventRecord(e1, L.stream);
+        const hipError_t err = hipEventSynchronize(e1);
+        if (err != hipSuccess) {
+            (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+            return fail(CATTUS_E_DEVICE, "hipEventSynchronize: %s", hipGetErrorString(err));
+        }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        elapsed += ms * 1e-3;
+        rate = flop / (ms * 1e-3) / 1e12;
+    }
+    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+    *tflops = rate;
+    return CATTUS_OK;
+}
+
 CATTUS_API int cattus_hip_planes_to_tensor_device(const uint64_t* d_planes, uint32_t n, uint32_t C, uint32_t plane_words,
                                                   uint32_t S, uint32_t batch, float* d_out, void* stream) {
     if (!d_planes || !d_out) return fail(CATTUS_E_INVALID, "NULL argument");

@@ -61,6 +61,10 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const StemInput* stem = nullptr,
                          int flags = 0);
 
+// Diagnostic: one launch of nothing but back-to-back MFMAs of the tower's kind (F16S: f16, BF16, F32: 32x32x2 f32), four
+// waves on each of `cus` workgroups, iters x 4 MFMAs per wave; `out` holds cus * 256 floats.  Returns the launch's FLOPs.
+double launch_mfma_sustain(Act act, int cus, int iters, float* out, hipStream_t st);
+
 // Forces the conv kernel's tile (1: 256 rows x 32 couts, 2: 256 rows x 64 couts; 0: chosen by grid size).
 void set_conv_cb(int v);
 // 2: the f16x2 conv never uses its 128-row workgroup (otherwise chosen for grids of <= 128 32-cout workgroups).

@@ -2584,4 +2584,57 @@ void launch_dense(const float* x, uint32_t x_stride, const float* wt, const floa
     else hipLaunchKernelGGL(policy_fc_kernel<DENSE_SCRUB>, grid, block, lds, st, x, x_stride, 0u, wt, bias, b, K, N, y);
 }
 
+// ------------------------------------------------------------------------------------------
+// Diagnostic: what the matrix pipe sustains (cattus_hip_mfma_sustained; bench.py's roofline.sustained)
+// ------------------------------------------------------------------------------------------
+// Nothing but back-to-back MFMAs of the tower's kind -- four independent accumulators per wave, operands in registers, no
+// memory traffic -- one wave per SIMD on every CU.  The nominal peaks (2.5 PFLOP/s f16 / bf16, 157 TFLOP/s f32) are 2.4 GHz
+// figures; under MFMA load the part's power management sets the clock, and this is the rate that leaves
+// (scripts/probes/mfma_peak_probe.hip is the stand-alone form; profiles/r03_mfma_peak_probe.txt).
+template <int KIND>  // 0: v_mfma_f32_32x32x16_f16, 1: ..._bf16, 2: v_mfma_f32_32x32x2_f32
+__global__ void __launch_bounds__(256) mfma_sustain_kernel(int iters, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    f16x8 a, b;
+    bf16x8 ab, bb;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a[i] = (_Float16)(0.001f * (lane + i)), b[i] = (_Float16)(0.002f * (lane - i));
+        ab[i] = (__bf16)(0.001f * (lane + i)), bb[i] = (__bf16)(0.002f * (lane - i));
+    }
+    const float af = 0.001f * lane, bf = 0.002f * (lane - 3);
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int it = 0; it < iters; it++) {
+        if constexpr (KIND == 0) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+        } else if constexpr (KIND == 1) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c3, 0, 0, 0);
+        } else {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c3, 0, 0, 0);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += c0[i] + c1[i] + c2[i] + c3[i];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
+// One launch: `cus` workgroups of four waves, iters x 4 MFMAs per wave; returns the FLOPs of the launch.
+double launch_mfma_sustain(Act act, int cus, int iters, float* out, hipStream_t st) {
+    const dim3 grid(cus), block(256);
+    if (act == Act::F16S) hipLaunchKernelGGL(mfma_sustain_kernel<0>, grid, block, 0, st, iters, out);
+    else if (act == Act::BF16) hipLaunchKernelGGL(mfma_sustain_kernel<1>, grid, block, 0, st, iters, out);
+    else hipLaunchKernelGGL(mfma_sustain_kernel<2>, grid, block, 0, st, iters, out);
+    const double flop_per_mfma = act == Act::F32 ? 2.0 * 32 * 32 * 2 : 2.0 * 32 * 32 * 16;
+    return (double)cus * 4 * iters * 4 * flop_per_mfma;
+}
+
 }  // namespace cattus

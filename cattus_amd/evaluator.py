@@ -44,6 +44,7 @@ ABI_SYMBOLS = [
     "cattus_hip_host_free",
     "cattus_hip_stats",
     "cattus_hip_time_tower",
+    "cattus_hip_mfma_sustained",
     "cattus_hip_planes_to_tensor",
     "cattus_hip_planes_to_tensor_device",
     "cattus_hip_last_error",
@@ -119,6 +120,7 @@ def load_library():
     L.cattus_hip_host_free.restype = None
     L.cattus_hip_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cattus_hip_time_tower.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.cattus_hip_mfma_sustained.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
     L.cattus_hip_planes_to_tensor.argtypes = [C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
     L.cattus_hip_planes_to_tensor_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.cattus_hip_last_error.restype = C.c_char_p
@@ -276,6 +278,12 @@ class HipEvaluator:
         s = Stats()
         _check(self._lib.cattus_hip_stats(self._h, C.byref(s)))
         return {name: getattr(s, name) for name, _ in Stats._fields_}
+
+    def mfma_sustained(self, seconds: float = 1.0) -> float:
+        """TFLOP/s the device's matrix pipe sustains on back-to-back MFMAs of this evaluator's tower kind (diagnostic)."""
+        t = C.c_double()
+        _check(self._lib.cattus_hip_mfma_sustained(self._h, float(seconds), C.byref(t)))
+        return t.value
 
     def time_tower(self, n: int, reps: int) -> tuple[float, int]:
         """(average device microseconds of one tower conv launch, launches per forward)."""

@@ -141,6 +141,12 @@ int cattus_hip_stats(cattus_eval* e, cattus_stats* out);
  * launches per forward. */
 int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, float* avg_launch_us, uint32_t* launches);
 
+/* Diagnostic: the rate (TFLOP/s) the matrix pipe of the evaluator's device sustains on nothing but back-to-back MFMAs of
+ * the evaluator's tower kind (f16x2: v_mfma_f32_32x32x16_f16, bf16: ..._bf16, f32: v_mfma_f32_32x32x2_f32) -- one wave per
+ * SIMD on every CU, operands in registers, launches of ~50 us repeated for `seconds` (0 < seconds <= 30), the last group's
+ * rate.  The nominal peaks are 2.4 GHz figures; under MFMA load the device's power management sets the clock. */
+int cattus_hip_mfma_sustained(cattus_eval* e, double seconds, double* tflops);
+
 /* Stand-alone planes_to_tensor (engine/src/net/mod.rs:121-156): host planes [n][C][plane_words]
  * -> host f32 tensor [batch][C][S][S], rows n..batch zero. */
 int cattus_hip_planes_to_tensor(int device, const uint64_t* planes, uint32_t n, uint32_t C, uint32_t plane_words,

@@ -32,3 +32,21 @@ def test_bench_prints_one_json_line_on_stdout():
     c = out["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert abs(out["value"] - 256 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_sustained_mfma_rate_is_a_sane_fraction_of_the_nominal_peak():
+    """cattus_hip_mfma_sustained (the `roofline.sustained` figure): between 40 % and 100 % of the nominal peak for every tower
+    kind, and the exact-f32 MFMA -- the least power-hungry -- closest to its own."""
+    import numpy as np  # noqa: F401
+
+    from cattus_amd.evaluator import HipEvaluator
+    from cattus_amd.weights import TTT, NetDesc, seeded_blob
+
+    blob = seeded_blob(NetDesc(**TTT, blocks=1, filters=64, vhc=8, phc=8), 3)
+    frac = {}
+    for dtype, nominal in (("f16x2", 2500.0), ("bf16", 2500.0), ("f32", 157.3)):
+        with HipEvaluator(blob, batch_size=4, plane_words=1, dtype=dtype) as ev:
+            frac[dtype] = ev.mfma_sustained(0.3) / nominal
+        assert 0.4 < frac[dtype] <= 1.02, (dtype, frac[dtype])
+    assert frac["f32"] > frac["f16x2"]
