@@ -18,33 +18,43 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // KIND 0: v_mfma_f32_32x32x16_f16, 1: v_mfma_f32_32x32x16_bf16, 2: v_mfma_f32_32x32x2_f32 (the exact-f32 tower's)
 template <int KIND>
 __global__ void __launch_bounds__(256) mfma_kernel(int iters, float* out, unsigned long long* clk) {
-    const int lane = threadIdx.x & 63;
-    half8 a, b;
-    bf16x8 ab, bb;
+    // four different operand pairs of pseudo-random values in [-1, 1): consecutive MFMAs see different inputs, as a conv's do
+    // (the same pair over and over toggles nothing between instructions and flatters the power)
+    uint32_t x = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    auto rnd = [&]() {
+        x = x * 1664525u + 1013904223u;
+        return (float)(int)(x >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    };
+    half8 a[4], b[4];
+    bf16x8 ab[4], bb[4];
+    float af[4], bf[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        a[i] = (_Float16)(0.001f * (lane + i)), b[i] = (_Float16)(0.002f * (lane - i));
-        ab[i] = (__bf16)(0.001f * (lane + i)), bb[i] = (__bf16)(0.002f * (lane - i));
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float u = rnd(), v = rnd();
+            a[q][i] = (_Float16)u, b[q][i] = (_Float16)v, ab[q][i] = (__bf16)u, bb[q][i] = (__bf16)v;
+        }
+        af[q] = rnd(), bf[q] = rnd();
     }
-    const float af = 0.001f * lane, bf = 0.002f * (lane - 3);
     floatx16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
         if constexpr (KIND == 0) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[1], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], b[2], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], b[3], c3, 0, 0, 0);
         } else if constexpr (KIND == 1) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[0], bb[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[1], bb[1], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[2], bb[2], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[3], bb[3], c3, 0, 0, 0);
         } else {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c3, 0, 0, 0);
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
