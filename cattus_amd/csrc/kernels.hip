@@ -281,7 +281,9 @@ struct StemPlanes<true> {
 //     (consumer wave: 1 x 2 tiles): twice the workgroups for the same layer, used while the full-size grid would
 //     leave more than half of the CUs empty (batches of <= 128 leaves on a 256-filter net).  Same MFMA shape and
 //     k order per output element, so the result does not depend on which of the two ran.
-template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2>
+// PBW: 32-pixel blocks per consumer wave.  2: the workgroup covers 256 tower rows; 1 (with CB = 1): 128 rows, 32 pixels per
+//     wave -- twice the workgroups and half the MFMA chain per wave, for grids that would otherwise leave CUs empty.
+template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2, int PBW = 2>
 __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
                            const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S, StemPlanes<STEM> sp) {
@@ -289,6 +291,10 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     constexpr int KC = 128 / (int)sizeof(T);
     constexpr int CPW = 32 * CB;          // output channels of this workgroup
     constexpr int WPLC = WPL * CB / 2;    // weight pieces per loader wave and step
+    static_assert(PBW == 2 || (PBW == 1 && CB == 1), "the 128-row workgroup exists for the 32-cout tile only");
+    constexpr int RW = 128 * PBW;         // tower rows of this workgroup
+    constexpr int PXW = 32 * PBW;         // pixels (rows) per consumer wave
+    constexpr int NHALF = PBW;            // an activation chunk is NHALF x 16 pieces of 1 KiB
     typedef typename Mfma<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -304,7 +310,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     int logical = blockIdx.x;
     if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     const int cout0 = (logical % ncb) * CPW;
-    const int row0 = (logical / ncb) * ROWS_PER_WG;  // first tower row (board * slots + pixel slot) of this workgroup
+    const int row0 = (logical / ncb) * RW;  // first tower row (board * slots + pixel slot) of this workgroup
 
     if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
@@ -317,8 +323,8 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         // ================================ loader waves ================================
         const int lw = wave - 4;
         const int prow = lane >> 3, pslot = lane & 7;
-        uint32_t off_w[WPLC], off_a[2][APL];
-        int dst_w[WPLC], dst_a[2][APL];
+        uint32_t off_w[WPLC], off_a[NHALF][APL];
+        int dst_w[WPLC], dst_a[NHALF][APL];
 #pragma unroll
         for (int i = 0; i < WPLC; i++) {
             const int pid = lw * WPLC + i;              // 0..12*CB-1: tap_i = pid / (4*CB), 8 cout rows each
@@ -328,10 +334,10 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             dst_w[i] = tap_i * 8192 + within * 1024;    // a tap's rows start 8 KiB apart whatever CB is
         }
 #pragma unroll
-        for (int g = 0; g < 2; g++)
+        for (int g = 0; g < NHALF; g++)
 #pragma unroll
             for (int i = 0; i < APL; i++) {
-                const int id = g * 16 + lw * APL + i;   // 0..31, 8 rows each of [4 boards][64 px]
+                const int id = g * 16 + lw * APL + i;   // 0..31 (0..15 at 128 rows), 8 rows each
                 const int row = id * 8 + prow;
                 const int c = pslot ^ ((row >> 1) & 7);
                 off_a[g][i] = (uint32_t)row * row_bytes + c * 16;
@@ -363,7 +369,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             const int row = lw * 64 + lane;
             const uint32_t grow = (uint32_t)(row0 + row), slots = BIG ? 128u : 64u;
             const uint32_t board = grow / slots, px = grow % slots;
-            const bool live = board < sp.n && (int)px < S * S;
+            const bool live = row < RW && board < sp.n && (int)px < S * S;
             typedef const __attribute__((address_space(1))) uint64_t* gu64p;
             const gu64p pl = (gu64p)(sp.planes + (size_t)(live ? board : 0) * sp.C * sp.w64 + (live ? (px >> 6) : 0));
             uint64_t words[MAXC];
@@ -381,12 +387,12 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                     const int c = sl * VEC + i;
                     vals[i] = (c < MAXC && ((words[c < MAXC ? c : 0] >> (px & 63)) & 1ull)) ? (T)1.0f : (T)0.0f;
                 }
-                *reinterpret_cast<f32x4*>(dstrow + ((sl ^ swz) << 4)) = *reinterpret_cast<f32x4*>(vals);
+                if (row < RW) *reinterpret_cast<f32x4*>(dstrow + ((sl ^ swz) << 4)) = *reinterpret_cast<f32x4*>(vals);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are written before the first barrier
         } else {
             issue_a(0, 0);
-            issue_a(0, 1);
+            if constexpr (NHALF == 2) issue_a(0, 1);
             issue_w(0);
             issue_w(1);
         }
@@ -415,7 +421,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                 issue_w(t + 2);
                 pending += WPLC;
             }
-            if (g < 2 && ch + 1 < nch) {
+            if (g < NHALF && ch + 1 < nch) {
                 issue_a(ch + 1, g);
                 pending += APL;
             }
@@ -434,12 +440,13 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 #endif
     const int r = lane & 31, h = lane >> 5;
     // pixel slot of this lane's two output columns within its board, and the LDS offset of the board's rows
-    const int pslot0 = BIG ? (wave & 1) * 64 : 0;
-    const int board_lds = BIG ? (wave >> 1) * 16384 : wave * 8192;
-    int ph[2], pw[2];
-    bool pvalid[2];
+    constexpr int SLOTS = BIG ? 128 : 64, WPB = SLOTS / PXW;  // consumer waves per board
+    const int pslot0 = (wave % WPB) * PXW;
+    const int board_lds = (wave / WPB) * SLOTS * 128;
+    int ph[PBW], pw[PBW];
+    bool pvalid[PBW];
 #pragma unroll
-    for (int pb = 0; pb < 2; pb++) {
+    for (int pb = 0; pb < PBW; pb++) {
         const int p = pslot0 + pb * 32 + r;
         ph[pb] = p / S;
         pw[pb] = p - ph[pb] * S;
@@ -454,11 +461,11 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
         for (int ks = 0; ks < 4; ks++) aaddr[ks][cb] = V2_LDS_W + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4);
     }
 
-    f32x16 acc[CB][2];
+    f32x16 acc[CB][PBW];
 #pragma unroll
     for (int i = 0; i < CB; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < PBW; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
@@ -471,14 +478,14 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 #pragma unroll
         for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
     // epilogue store layout: a pixel row of the tile is CPW couts = LPR lanes x 8 couts; 64 / LPR rows per trip
-    constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = 64 / RPT;
+    constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = PXW / RPT;
     const int prow = lane / LPR, cg = lane % LPR;
     constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2;
     T resv[EIT][8];
     if (RES_EARLY) {
 #pragma unroll
         for (int i = 0; i < EIT; i++) {
-            const size_t off = ((size_t)row0 + wave * 64 + i * RPT + prow) * (size_t)cout + cout0 + cg * 8;
+            const size_t off = ((size_t)row0 + wave * PXW + i * RPT + prow) * (size_t)cout + cout0 + cg * 8;
             *reinterpret_cast<f32x4*>(resv[i]) = *reinterpret_cast<const f32x4*>(res + off);
         }
     }
@@ -487,6 +494,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     // fragments feeding 2 CB MFMAs.  Fragments are read AHEAD stages before the MFMAs that consume them
     // (register ring) so the LDS latency hides under the MFMAs in between.
     constexpr int AHEAD = CB == 2 ? 2 : 3, RING = AHEAD + 1;
+    constexpr bool MEET = BIG || PBW == 1;  // more than one consumer wave per board
     int opaque = 0;
     for (int ch = 0; ch < nch; ch++) {
         const int abase = V2_LDS_ACT + (ch & 1) * 32768 + board_lds;
@@ -504,11 +512,11 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             constexpr int dummy = 0;
             (void)dummy;
             const int wslab = g * V2_SLAB;  // ring slot of step ch*3+g is g
-            int baddr[3][2][4];
+            int baddr[3][PBW][4];
 #pragma unroll
             for (int dxi = 0; dxi < 3; dxi++)
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) {
+                for (int pb = 0; pb < PBW; pb++) {
                     const int hh = ph[pb] + (g - 1) + opaque, ww = pw[pb] + dxi - 1;
                     const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
                     const int q = hh * S + ww;
@@ -517,28 +525,28 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
                 }
-            frag fa[RING][CB], fb[RING][2];
-            auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[2]) {
+            frag fa[RING][CB], fb[RING][PBW];
+            auto load_stage = [&](int i, frag (&a)[CB], frag (&b)[PBW]) {
                 const int dxi = i >> 2, ks = i & 3;
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++)
                     a[cb] = *reinterpret_cast<const frag*>(smem + aaddr[ks][cb] + (wslab + dxi * 8192));
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][ks]);
+                for (int pb = 0; pb < PBW; pb++) b[pb] = *reinterpret_cast<const frag*>(smem + baddr[dxi][pb][ks]);
             };
 #pragma unroll
             for (int i = 0; i < AHEAD; i++) load_stage(i, fa[i % RING], fb[i % RING]);
-            __builtin_amdgcn_sched_group_barrier(0x100, (CB + 2) * AHEAD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (CB + PBW) * AHEAD, 0);
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 if (i + AHEAD < 12) load_stage(i + AHEAD, fa[(i + AHEAD) % RING], fb[(i + AHEAD) % RING]);
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-                    for (int pb = 0; pb < 2; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
+                    for (int pb = 0; pb < PBW; pb++) Mfma<T>::mac(fa[i % RING][cb], fb[i % RING][pb], acc[cb][pb]);
                 // pin the issue order: this stage's look-ahead reads, then its MFMAs
-                if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, CB + 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, CB * 2 * (sizeof(T) == 2 ? 1 : 4), 0);
+                if (i + AHEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, CB + PBW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CB * PBW * (sizeof(T) == 2 ? 1 : 4), 0);
             }
         }
     }
@@ -550,14 +558,14 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     // (XOR-swizzled 16-byte slots), then every lane owns 8 consecutive couts of one pixel: one
     // 16/32-byte residual load and one 16/32-byte store per lane and pixel row, whole 128-byte lines.
     STAMP(2);
-    if (BIG) {
+    if (MEET) {
         // the staging region below holds pixel rows the OTHER wave of this board may still be reading as
         // neighbours in its last step: meet first (the loader waves have left; a barrier counts live waves)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     {
-        const size_t wrow0 = (size_t)row0 + wave * 64;  // first tower row of this wave's tile
-        const int tile0 = V2_LDS_ACT + wave * 8192;  // px 0..31; px 32..63 live 32768 bytes further
+        const size_t wrow0 = (size_t)row0 + wave * PXW;  // first tower row of this wave's tile
+        const int tile0 = V2_LDS_ACT + wave * PXW * 128;  // px 0..31; px 32..63 live 32768 bytes further (CB = 2)
         // skip-connection rows in the final (pixel row, 8 couts) layout, requested before the transpose
         if (HAS_RES && !RES_EARLY) {
 #pragma unroll
@@ -577,7 +585,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
 #pragma unroll
         for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-            for (int pb = 0; pb < 2; pb++)
+            for (int pb = 0; pb < PBW; pb++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const f32x4 bv = biasv[cb][g];
@@ -1430,6 +1438,13 @@ static hipError_t conv_attrs_for() {
     CATTUS_ATTR_CB(1)
     CATTUS_ATTR_CB(2)
 #undef CATTUS_ATTR_CB
+    // the 128-row workgroups of the 32-cout tile
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, false, false, 1, 1>));
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, true, false, false, 1, 1>));
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, true, false, 1, 1>));
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, true, true, false, 1, 1>));
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, false, true, 1, 1>));
+    set(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<T, false, true, true, 1, 1>));
     return err;
 }
 static hipError_t split_attrs() {
@@ -1520,13 +1535,29 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 #undef CATTUS_LAUNCH_SPLIT
         return;
     }
+    // 128 rows x 32 couts per workgroup while even the 32-cout grid would leave half of the CUs empty (as the split conv does)
+    const bool half_rows2 = cb == 1 && ((grid.x <= 128 && g_conv_pbw != 2) || g_conv_pbw == 1);
+    const dim3 grid_half2(grid.x * 2);
 #define CATTUS_LAUNCH_CONV2(T, R, BIG, CBV)                                                               \
-    hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                          (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{})
+    do {                                                                                                  \
+        if (half_rows2 && CBV == 1)                                                                       \
+            hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, 1, 1>), grid_half2, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                                  (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{}); \
+        else                                                                                              \
+            hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                                  (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{}); \
+    } while (0)
 #define CATTUS_LAUNCH_STEM(T, BIG, CBV)                                                                   \
-    hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                          (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
-                          StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64})
+    do {                                                                                                  \
+        if (half_rows2 && CBV == 1)                                                                       \
+            hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, 1, 1>), grid_half2, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                                  (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
+                                  StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64});           \
+        else                                                                                              \
+            hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
+                                  (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
+                                  StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64});           \
+    } while (0)
 #define CATTUS_LAUNCH_CONV2_CB(T, CBV)                            \
     do {                                                          \
         if (stem) {                                               \

@@ -327,10 +327,11 @@ def test_half_cout_workgroups_equal_full_ones(game, desc, words, n, dtype, monke
     ("hex11", dict(**hex_game(11), blocks=2, filters=128, vhc=16, phc=16), 2, 21),   # 128-slot boards: one board per workgroup
     ("ttt", dict(planes=3, board=3, moves=9, blocks=2, filters=64, vhc=8, phc=8), 1, 7),
 ])
-def test_f16x2_half_row_workgroups_equal_full_ones(game, desc, words, n, monkeypatch):
-    """Batches that would leave half of the CUs empty run the f16x2 conv on 128-row x 32-cout workgroups (32 pixels per
+@pytest.mark.parametrize("dtype", ["f16x2", "f32", "bf16"])
+def test_half_row_workgroups_equal_full_ones(game, desc, words, n, dtype, monkeypatch):
+    """Batches that would leave half of the CUs empty run the conv layers on 128-row x 32-cout workgroups (32 pixels per
     consumer wave); CATTUS_CONV_PBW=2 keeps the 256-row ones, =1 forces the small ones wherever the tile is 32 couts: same
-    MFMA sequence per output, same bits."""
+    MFMA sequence per output, same bits (and, in f32, the oracle's)."""
     d = NetDesc(**desc)
     blob = seeded_blob(d, 29)
     rng = np.random.default_rng(13)
@@ -345,10 +346,13 @@ def test_f16x2_half_row_workgroups_equal_full_ones(game, desc, words, n, monkeyp
             monkeypatch.delenv("CATTUS_CONV_PBW")
         else:
             monkeypatch.setenv("CATTUS_CONV_PBW", pbw)
-        with HipEvaluator(blob, batch_size=n, plane_words=words, dtype="f16x2") as ev:
+        with HipEvaluator(blob, batch_size=n, plane_words=words, dtype=dtype) as ev:
             outs.append(ev.eval(planes))
     for o in outs[1:]:
         assert (o[0] == outs[0][0]).all() and (o[1] == outs[0][1]).all()
+    if dtype == "f32":
+        want_p, want_v = oracle.OracleNet(blob).forward(planes[:6])
+        assert (outs[2][0][:6] == want_p).all() and (outs[2][1][:6] == want_v).all()
 
 
 def test_wide_heads_take_the_generic_path_and_refuse_bf16():
