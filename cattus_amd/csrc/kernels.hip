@@ -645,9 +645,9 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 }
 #endif
 
-int g_conv_cb = 0;  // 0: by grid size; 1 / 2: 32 / 64 couts per workgroup (CATTUS_CONV_CB, A/B runs and the equality test)
+static std::atomic<int> g_conv_cb{0};  // 0: by grid size; 1 / 2: 32 / 64 couts per workgroup (CATTUS_CONV_CB, A/B runs and the equality test)
 void set_conv_cb(int v) { g_conv_cb = (v == 1 || v == 2) ? v : 0; }
-static std::atomic<int> g_conv_pbw{0};  // 2: never / 1: whenever the tile is 32 couts -- the 128-row workgroup of the f16x2 conv (A/B, tests)
+static std::atomic<int> g_conv_pbw{0};  // 2: never / 1: whenever the tile is 32 couts -- the 128-row workgroup of the conv kernels (A/B, tests)
 void set_conv_pbw(int v) { g_conv_pbw = (v == 1 || v == 2) ? v : 0; }
 
 
@@ -1489,7 +1489,7 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
     // 256 rows x 64 couts per workgroup; 256 rows x 32 couts while that grid would leave half of the CUs empty
     const uint32_t full_grid = (bpad * slots / ROWS_PER_WG) * (cout / COUT_PER_WG);
     int cb = full_grid <= 128 ? 1 : 2;
-    if (g_conv_cb) cb = g_conv_cb;
+    if (const int forced = g_conv_cb.load(std::memory_order_relaxed)) cb = forced;
     const dim3 grid(full_grid * (cb == 1 ? 2 : 1));
     if (act == Act::F16S) {
         typedef _Float16 H;
@@ -1499,7 +1499,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
             abort();
         }
         // 128 rows x 32 couts per workgroup while even the 32-cout grid would leave half of the CUs empty (register ring only)
-        const bool half_rows = wfrag && cb == 1 && ((grid.x <= 128 && g_conv_pbw != 2) || g_conv_pbw == 1);
+        const int pbw_forced = g_conv_pbw.load(std::memory_order_relaxed);
+        const bool half_rows = wfrag && cb == 1 && ((grid.x <= 128 && pbw_forced != 2) || pbw_forced == 1);
         const dim3 grid_half(grid.x * 2);
 #define CATTUS_LAUNCH_SPLIT(R, BIG, STEMV, CBV, SPV)                                                                                   \
     do {                                                                                                                               \
@@ -1536,7 +1537,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
         return;
     }
     // 128 rows x 32 couts per workgroup while even the 32-cout grid would leave half of the CUs empty (as the split conv does)
-    const bool half_rows2 = cb == 1 && ((grid.x <= 128 && g_conv_pbw != 2) || g_conv_pbw == 1);
+    const int pbw_forced2 = g_conv_pbw.load(std::memory_order_relaxed);
+    const bool half_rows2 = cb == 1 && ((grid.x <= 128 && pbw_forced2 != 2) || pbw_forced2 == 1);
     const dim3 grid_half2(grid.x * 2);
 #define CATTUS_LAUNCH_CONV2(T, R, BIG, CBV)                                                               \
     do {                                                                                                  \
