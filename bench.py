@@ -299,7 +299,7 @@ def search_threads(sp, world: int) -> int:
 def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, max_game_plies, keep_records, pool, torch, dev):
     """Real self-play on this rank's shard of the games: C++ search + evaluation cache + this GPU's evaluator
     through cattus_hip_eval (host buffers, PCIe included), the reference's self-play settings.  With `pool`
-    the records of all ranks are pooled by cattus_amd.dist.pool_records (all-gather) and the counters
+    the records of all ranks are pooled on rank 0 by cattus_amd.dist.pool_records (gather) and the counters
     all-reduced, inside the timed region."""
     from cattus_amd import dist as cdist
     from cattus_amd import selfplay as sp
@@ -324,12 +324,13 @@ def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, ma
             import torch.distributed as dist
 
             t1 = time.perf_counter()
-            recs, _meta = cdist.pool_records(res["record_bytes"], res["record_meta"], device=dev)  # dev: where the collectives run
+            recs, _meta = cdist.pool_records(res["record_bytes"], res["record_meta"], device=dev)  # on rank 0; dev: where the collectives run
             tot = cdist.reduce_counters(res, device=dev)
             torch.cuda.synchronize()
             pool_s = time.perf_counter() - t1
-            pooled = dict(records=int(len(recs)), bytes=int(recs.size), draws=tot["draws"], p1=tot["player1_wins"], p2=tot["player2_wins"])
-            assert len(recs) == tot["positions"]
+            if recs is not None:  # rank 0 holds the pooled set
+                pooled = dict(records=int(len(recs)), bytes=int(recs.size), draws=tot["draws"], p1=tot["player1_wins"], p2=tot["player2_wins"])
+                assert len(recs) == tot["positions"]
     return dict(seconds=play_s + pool_s, play_seconds=play_s, pool_seconds=pool_s, games=games, node_evals=res["node_evals"],
                 batches=res["activation_count"], positions=res["positions"], threads=threads, slots=slots, sims=sims,
                 adjudicated=int(res["adjudicated"]), cache_hits=res["cache_hits"],
@@ -376,6 +377,49 @@ def reduce_leg(leg, torch, dev, world):
     return out
 
 
+# ------------------------------------------------------------------------------------------ ranks
+
+
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """One process per GPU (the fan-out of training/self-play/src/self_play.rs:109-137, over processes instead of threads):
+    start `python -m torch.distributed.run --nproc-per-node n bench.py <argv>` as a CHILD of this process, pass rank 0's JSON
+    line through on stdout and return the launcher's exit status.  Never an exec: the caller has not touched the GPU, and a
+    process that has must not be replaced."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")             # what torchrun would set (and warn about); the ranks size their own pools
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for line in proc.stdout:
+        try:
+            if "metric" in json.loads(line):
+                lines.append(line.strip())
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(line)  # anything else a rank or a library wrote to stdout
+    rc = proc.wait()
+    if len(lines) != 1:
+        print(f"bench.py: expected one result line from rank 0, got {len(lines)} (launcher exit status {rc})", file=sys.stderr)
+        return rc or 1
+    out = json.loads(lines[0])
+    if out.get("n_gpus") != n:
+        print(f"bench.py: the ranks reported n_gpus={out.get('n_gpus')}, asked for {n}", file=sys.stderr)
+        return rc or 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return rc
+
+
 # ------------------------------------------------------------------------------------------ main
 
 
@@ -402,7 +446,20 @@ def main():
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 (throughput mode) object")
     ap.add_argument("--settle-seconds", type=float, default=0.4,
                     help="untimed steps run for this long IN FRONT of the W warm-up steps (the clock governor needs longer than W steps to settle); 0 = none")
+    ap.add_argument("--side-legs-timeout", type=float, default=900.0,
+                    help="seconds the legs behind the headline may take before a watchdog prints the line with what is there and ends the process")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: this process -- which has not imported torch, loaded
+            # libcattus_hip.so or made any HIP call -- starts N fresh ranks and relays rank 0's line
+            os.dup2(json_fd, 1)
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks: "
+                         "refusing to report a line for a job of another size")
 
     import torch
 
@@ -417,6 +474,9 @@ def main():
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    if not rehearsal and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but this node shows {torch.cuda.device_count()} devices "
+                         "(BENCH_REHEARSAL=1 puts every rank on device 0, for plumbing tests only)")
     # one process per GPU: a disjoint share of the host's CPUs for this rank, on its GPU's NUMA node where sysfs tells
     # (before any thread of the evaluator or the search exists; cattus_amd/affinity.py)
     from cattus_amd import affinity
@@ -428,14 +488,28 @@ def main():
 
     headline = args.workload == "chess20x256"
     want_pg = world > 1 or (headline and args.selfplay_seconds > 0)  # config 4's leg pools records over RCCL, also on one rank
+    pg_note = None
     if want_pg:
-        if rehearsal:
-            dist.init_process_group("gloo")
-        elif world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1,
-                                    device_id=torch.device("cuda", local_rank))
+        import datetime
+
+        # every collective of this job carries a deadline: a rank that died leaves the others an error, not a hang
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("BENCH_PG_TIMEOUT", "600")))
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo", timeout=pg_timeout)
+            elif world > 1:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
+            else:
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1,
+                                        device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
+            pg_note = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "timeout_s": pg_timeout.total_seconds()}
+        except Exception as exc:  # noqa: BLE001
+            if world > 1:
+                raise  # N ranks without a process group cannot report one job
+            # one rank: only the config-4 leg wanted it; the headline does not
+            pg_note = {"error": f"{type(exc).__name__}: {exc}"}
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: process group of {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from cattus_amd.evaluator import HipEvaluator
 
@@ -641,74 +715,10 @@ def main():
 
     main_r = time_evaluator(args.dtype, args.steps, args.warmup, args.lanes, args.settle_seconds)
 
-    sides = {}
-    for dtype, skip, div in (("bf16", args.no_bf16, 1), ("f32", args.no_f32, 10)):
-        if dtype == args.dtype or skip:
-            continue
-        k = max(5, args.steps // div)
-        r = time_evaluator(dtype, k, max(2, args.warmup // div), settle_s=0.2 if dtype == "bf16" else 0.0)
-        if rank == 0:
-            sides[dtype] = side_object(dtype, r)
-
-    # ---- reduced-cost towers vs f32 at SEARCH level (rank 0): 800-sim searches of the same positions with each tower
-    agreement = None
-    if headline and args.agreement_plies > 0 and rank == 0 and args.dtype != "f32":
-        from cattus_amd import agreement as ag
-        from cattus_amd import selfplay as sp
-
-        games = 16
-        t0 = time.perf_counter()
-        with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="f32", device=local_rank, flush_us=100) as ev32:
-            cfg = sp.make_config(sim_num=800, temperature_policy=[(9999, 0.0)], cache_size=1000000)
-            opens = ag.random_openings("chess", games, 2, seed=7)
-            ta = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev32), opens, 2, args.agreement_plies)
-        lines = [op + [c for c, _ in t] for op, t in zip(opens, ta)]
-        agreement = {}
-        for dtype in [args.dtype] + ([] if args.no_bf16 or args.dtype == "bf16" else ["bf16"]):
-            with HipEvaluator(blob, batch_size=games, plane_words=1, dtype=dtype, device=local_rank, flush_us=100) as evx:
-                tb = ag.run_traces("chess", cfg, sp.Net.hip_batched(evx), lines, 2, args.agreement_plies)
-            agreement[dtype] = ag.compare_traces(ta, tb)
-        agreement.update(games=games, sims_per_move=800, searched_plies_per_game=args.agreement_plies, seconds=time.perf_counter() - t0,
-                         note="f32 plays; each tower searches the same positions (teacher-forced, trees carried over); greedy move choice, noise "
-                              "off. tests/test_search_parity_gpu.py runs 16 plies per game and bounds these numbers; larger samples: "
-                              "profiles/r03_search_agreement.json")
-
-    # ---- end-to-end self-play legs (all ranks; each plays its own shard of the games)
-    sp_out = sp_full = sp_c4 = None
-    if headline and args.selfplay_seconds > 0:
-        from cattus_amd import selfplay as sp
-
-        threads = search_threads(sp, world)
-        # BASELINE config 3 as written: 800 sims/move, batch 256; 1536 concurrent games (two batches in flight and four
-        # more in the making); every game is cut after `plies` plies so that the leg fits its time budget (a whole
-        # 800-sim game of ~290 plies costs ~170 k evaluations)
-        capacity = min(EVAL_CAPACITY[args.dtype], threads * 60e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
-        conc = 1536
-        plies = int(max(3, min(64, args.selfplay_seconds * capacity / (conc * 0.75 * args.selfplay_sims))))
-        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=conc, slots=conc, sims=args.selfplay_sims, max_game_plies=plies,
-                           keep_records=False, pool=False, torch=torch, dev=cdev)
-        sp_out = reduce_leg(leg, torch, cdev, world)
-        sp_out.update(max_game_plies=plies, settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype,
-                      note="bounded sample: every game is adjudicated after max_game_plies plies; games_per_hour_estimate = plies_per_sec "
-                           "* 3600 / (plies per whole game measured in selfplay_full_games) -- an ESTIMATE; measured whole games at 800 sims: "
-                           "profiles/r03_e2e_whole_games_800sims.json")
-        # whole games, reduced simulation count: a measured games/hour
-        full_sims = 64
-        full_games = int(min(1024, max(64, 25.0 * capacity / (190.0 * full_sims)))) // 2 * 2
-        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=full_games, slots=full_games, sims=full_sims, max_game_plies=0,
-                           keep_records=False, pool=False, torch=torch, dev=cdev)
-        sp_full = reduce_leg(leg, torch, cdev, world)
-        sp_full.update(games_per_hour=sp_full["games"] * 3600.0 / sp_full["seconds"], settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype)
-        sp_out["games_per_hour_estimate"] = sp_out["plies_per_sec"] * 3600.0 / max(1.0, sp_full["plies_per_game"])
-        # BASELINE config 4's shape: 64 concurrent games per GPU (sequential search: at most 64 leaves per batch), records
-        # kept and pooled over RCCL (all-gather) with the counters all-reduced, all inside the timed region
-        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=64, slots=64, sims=args.selfplay_sims, max_game_plies=6,
-                           keep_records=True, pool=True, torch=torch, dev=cdev)
-        sp_c4 = reduce_leg(leg, torch, cdev, world)
-        sp_c4.update(max_game_plies=6, pool_seconds=leg["pool_seconds"], pooled=leg["pooled"], settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype,
-                     note="64 games per GPU, records all-gathered and counters all-reduced through torch.distributed 'nccl' (= RCCL) inside "
-                          "the timed region; one leaf per tree in flight, so a batch holds at most 64 leaves")
-
+    # ---- the headline is complete here.  Everything behind it is a side leg: each runs inside run_leg(), so an exception
+    # becomes an {"error": ...} object in the line instead of taking the headline with it, and a watchdog prints the line
+    # with what is there if the legs hang (a rank that died inside a collective of a leg leaves the others waiting).
+    out = {}
     if rank == 0:
         value = world * batch * args.steps / main_r["elapsed"]
         out = {
@@ -739,6 +749,7 @@ def main():
             "effective_warmup_steps": args.warmup + main_r["settle_steps"],
             "roofline": roofline(args.dtype, main_r),
             "host": {"cpus_of_this_rank": len(cpu_share), "ranks_on_this_node": local_world},
+            "process_group": pg_note,
         }
         out["whole_step_mfma_frac"] = d.flops_per_position() * batch / (main_r["elapsed"] / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype]
         if main_r["settle_ms"] is not None:
@@ -750,22 +761,150 @@ def main():
                 "ms_per_step": main_r["elapsed2"] / args.steps * 1e3,
                 "note": "same K steps alternating between the evaluator's two lanes on two streams",
             }
-        out.update(sides)
-        if agreement is not None:
-            out["search_agreement"] = agreement
+
+    import threading
+
+    emit_lock = threading.Lock()
+    emitted = [False]
+
+    def emit():
+        """Rank 0 writes THE line, once."""
+        with emit_lock:
+            if emitted[0] or rank != 0:
+                return
+            emitted[0] = True
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    def watchdog():
+        # the side legs hang (a collective whose peer is gone, a wedged leg): the headline is measured -- print it and leave
+        print(f"bench.py: rank {rank}: side legs exceeded --side-legs-timeout {args.side_legs_timeout:.0f} s; "
+              "printing the line with what is there", file=sys.stderr, flush=True)
+        out["side_legs_error"] = f"watchdog: side legs exceeded {args.side_legs_timeout:.0f} s"
+        emit()
+        os._exit(0 if rank == 0 else 3)
+
+    timer = threading.Timer(args.side_legs_timeout, watchdog)
+    timer.daemon = True
+    timer.start()
+
+    def run_leg(name, fn):
+        """-> fn()'s result, or None after recording {"error": ...} under `name` (rank 0) when it raised."""
+        try:
+            return fn()
+        except Exception as exc:  # noqa: BLE001 - a side leg must not take the headline with it
+            import traceback
+
+            traceback.print_exc()
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            return None
+
+    for dtype, skip, div in (("bf16", args.no_bf16, 1), ("f32", args.no_f32, 10)):
+        if dtype == args.dtype or skip:
+            continue
+        k = max(5, args.steps // div)
+
+        def side(dtype=dtype, k=k, div=div):
+            r = time_evaluator(dtype, k, max(2, args.warmup // div), settle_s=0.2 if dtype == "bf16" else 0.0)
+            return side_object(dtype, r) if rank == 0 else None
+
+        obj = run_leg(dtype, side)
+        if obj is not None:
+            out[dtype] = obj
+
+    # ---- reduced-cost towers vs f32 at SEARCH level (rank 0): 800-sim searches of the same positions with each tower
+    def agreement_leg():
+        from cattus_amd import agreement as ag
+        from cattus_amd import selfplay as sp
+
+        games = 16
+        t0 = time.perf_counter()
+        with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="f32", device=local_rank, flush_us=100) as ev32:
+            cfg = sp.make_config(sim_num=800, temperature_policy=[(9999, 0.0)], cache_size=1000000)
+            opens = ag.random_openings("chess", games, 2, seed=7)
+            ta = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev32), opens, 2, args.agreement_plies)
+        lines = [op + [c for c, _ in t] for op, t in zip(opens, ta)]
+        agreement = {}
+        for dtype in [args.dtype] + ([] if args.no_bf16 or args.dtype == "bf16" else ["bf16"]):
+            with HipEvaluator(blob, batch_size=games, plane_words=1, dtype=dtype, device=local_rank, flush_us=100) as evx:
+                tb = ag.run_traces("chess", cfg, sp.Net.hip_batched(evx), lines, 2, args.agreement_plies)
+            agreement[dtype] = ag.compare_traces(ta, tb)
+        agreement.update(games=games, sims_per_move=800, searched_plies_per_game=args.agreement_plies, seconds=time.perf_counter() - t0,
+                         note="f32 plays; each tower searches the same positions (teacher-forced, trees carried over); greedy move choice, noise "
+                              "off. tests/test_search_parity_gpu.py runs 16 plies per game and bounds these numbers; larger samples: "
+                              "profiles/r03_search_agreement.json")
+        return agreement
+
+    if headline and args.agreement_plies > 0 and rank == 0 and args.dtype != "f32":
+        obj = run_leg("search_agreement", agreement_leg)
+        if obj is not None:
+            out["search_agreement"] = obj
+
+    # ---- end-to-end self-play legs (all ranks; each plays its own shard of the games)
+    def selfplay_legs():
+        from cattus_amd import selfplay as sp
+
+        threads = search_threads(sp, world)
+        # BASELINE config 3 as written: 800 sims/move, batch 256; 1536 concurrent games (two batches in flight and four
+        # more in the making); every game is cut after `plies` plies so that the leg fits its time budget (a whole
+        # 800-sim game of ~290 plies costs ~170 k evaluations)
+        capacity = min(EVAL_CAPACITY[args.dtype], threads * 60e3)  # evaluations/s this rank can expect: GPU-bound or host-bound
+        conc = 1536
+        plies = int(max(3, min(64, args.selfplay_seconds * capacity / (conc * 0.75 * args.selfplay_sims))))
+        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=conc, slots=conc, sims=args.selfplay_sims, max_game_plies=plies,
+                           keep_records=False, pool=False, torch=torch, dev=cdev)
+        sp_out = reduce_leg(leg, torch, cdev, world)
+        sp_out.update(max_game_plies=plies, settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype,
+                      note="bounded sample: every game is adjudicated after max_game_plies plies; games_per_hour_estimate = plies_per_sec "
+                           "* 3600 / (plies per whole game measured in selfplay_full_games) -- an ESTIMATE; measured whole games at 800 sims: "
+                           "profiles/r03_e2e_whole_games_800sims.json")
+        out["selfplay"] = sp_out
+        # whole games, reduced simulation count: a measured games/hour
+        full_sims = 64
+        full_games = int(min(1024, max(64, 25.0 * capacity / (190.0 * full_sims)))) // 2 * 2
+        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=full_games, slots=full_games, sims=full_sims, max_game_plies=0,
+                           keep_records=False, pool=False, torch=torch, dev=cdev)
+        sp_full = reduce_leg(leg, torch, cdev, world)
+        sp_full.update(games_per_hour=sp_full["games"] * 3600.0 / sp_full["seconds"], settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype)
+        sp_out["games_per_hour_estimate"] = sp_out["plies_per_sec"] * 3600.0 / max(1.0, sp_full["plies_per_game"])
+        out["selfplay_full_games"] = sp_full
+        # BASELINE config 4's shape: 64 concurrent games per GPU (sequential search: at most 64 leaves per batch), records
+        # kept and pooled over RCCL (gather to rank 0) with the counters all-reduced, all inside the timed region
+        pool = dist.is_initialized()
+        leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=64, slots=64, sims=args.selfplay_sims, max_game_plies=6,
+                           keep_records=True, pool=pool, torch=torch, dev=cdev)
+        sp_c4 = reduce_leg(leg, torch, cdev, world)
+        sp_c4.update(max_game_plies=6, pool_seconds=leg["pool_seconds"], pooled=leg["pooled"], settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype,
+                     note="64 games per GPU, records gathered on rank 0 and counters all-reduced through torch.distributed 'nccl' (= RCCL) inside "
+                          "the timed region; one leaf per tree in flight, so a batch holds at most 64 leaves"
+                          + ("" if pool else "; NO process group came up on this box (see process_group): nothing was pooled"))
+        out["selfplay_config4"] = sp_c4
+
+    if headline and args.selfplay_seconds > 0:
+        run_leg("selfplay_legs", selfplay_legs)
+
+    if rank == 0:
         if headline:
-            from cattus_amd import evaluator as ev_mod
+            def pack_leg():
+                from cattus_amd import evaluator as ev_mod
 
-            out["roofline_plane_pack"] = pack_roofline(torch, ev_mod.load_library(), dev, stream)
-        if sp_out is not None:
-            out["selfplay"], out["selfplay_full_games"], out["selfplay_config4"] = sp_out, sp_full, sp_c4
+                return pack_roofline(torch, ev_mod.load_library(), dev, stream)
+
+            obj = run_leg("roofline_plane_pack", pack_leg)
+            if obj is not None:
+                out["roofline_plane_pack"] = obj
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(blob, planes)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+            obj = run_leg("cpu_baseline", lambda: cpu_baseline(blob, planes))
+            if obj is not None:
+                out["cpu_baseline"] = obj
+    timer.cancel()
+    emit()
 
-    if want_pg:
-        dist.destroy_process_group()
+    if dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 - the line is out; a peer that is gone must not turn the exit status red
+            pass
 
 
 if __name__ == "__main__":

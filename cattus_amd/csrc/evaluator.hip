@@ -244,6 +244,10 @@ struct cattus_eval {
     bool pack_separately = false;  // CATTUS_FUSED_STEM=0: plane pack as its own launch in front of the stem (A/B, tests)
     int t64_force_ch = 0;          // CATTUS_T64_CH=2|4: workgroup shape of the resident tower (A/B runs, the row-split test)
     bool split_wfrag = true;       // CATTUS_SPLIT_W=0: f16x2 weights through the LDS ring (conv3x3_split_kernel) instead of the register ring
+    // tile-forcing switches (CATTUS_CONV_CB, CATTUS_CONV_PBW: A/B runs, the tile-equality tests) and the f16 towers' saturation
+    // counter: this evaluator's own -- a second evaluator in the process (model1 vs model2) neither re-tiles nor shares them
+    ConvOpts conv_opts;
+    DevBuf d_saturated;
     bool t64_layer_steps = true;   // CATTUS_T64_LS=0: three barriers per layer in the one-board resident tower
     int device = 0;
 
@@ -351,6 +355,29 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
                 }
             return L.wf.upload(wf.data(), wf.size() * 2);
         }
+        return L.w.upload(w.data(), w.size() * 2);
+    }
+    if (e->act == Act::F16) {
+        // Single-term f16: w' = f16(w * 2^s), s per output channel as for the split tower (largest |w'| in [2^10, 2^11): no
+        // weight of the channel becomes a subnormal unless it is 2^-24 of the largest), rows [9][cout_pad][cin_pad] as in the
+        // bf16 tower; the bias buffer is [cout_pad biases | cout_pad inverse scales].
+        std::vector<float> b((size_t)2 * cout_pad, 0.0f);
+        memcpy(b.data(), f.b.data(), cout * sizeof(float));
+        std::vector<_Float16> w((size_t)9 * cout_pad * cin_pad, (_Float16)0.0f);
+        for (uint32_t co = 0; co < cout_pad; co++) {
+            float m = 0.0f;
+            if (co < cout)
+                for (uint32_t t = 0; t < 9; t++)
+                    for (uint32_t ci = 0; ci < cin; ci++) m = std::max(m, fabsf(f.w[((size_t)t * cout + co) * cin + ci]));
+            int sh = 0;
+            if (m > 0.0f && std::isfinite(m)) sh = std::min(100, std::max(-100, 10 - ilogbf(m)));
+            b[cout_pad + co] = ldexpf(1.0f, -sh);
+            if (co >= cout) continue;
+            for (uint32_t t = 0; t < 9; t++)
+                for (uint32_t ci = 0; ci < cin; ci++)
+                    w[((size_t)t * cout_pad + co) * cin_pad + ci] = (_Float16)ldexpf(f.w[((size_t)t * cout + co) * cin + ci], sh);
+        }
+        if ((rc = L.b.upload(b.data(), b.size() * sizeof(float)))) return rc;
         return L.w.upload(w.data(), w.size() * 2);
     }
     std::vector<float> b(cout_pad, 0.0f);
@@ -521,7 +548,8 @@ int build(cattus_eval* e, const float* p) {
 
     // activations
     const size_t bp_ = e->bpad, B = e->cfg.max_batch;
-    const size_t esz = e->tuned ? (size_t)act_bytes(e->act) : 4;
+    // bytes per channel of the tower buffers; the f16 towers' last layer writes f32 rows into one of them
+    const size_t esz = e->tuned ? (act_f16_family(e->act) ? 4 : (size_t)act_bytes(e->act)) : 4;
     const size_t hesz = e->tuned ? (size_t)act_bytes(head_act(e->act)) : 4;  // element of the head activations
     const size_t slots = e->tuned ? e->slots : hw;
     const size_t FA = e->tuned ? FP : F;  // channels of the tower buffers
@@ -601,19 +629,19 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             if (!fused_stem) launch_pack_planes_nhwc(e->act, d_planes, n, nb, d.planes, w64, S, e->cpad0, L.x0.p, st);
             hipEvent_t s0 = ev(false), s1 = ev(true);
             // the split tower hands its last layer to the f32 head kernels as plain f32 rows
-            const int last_flags = e->act == Act::F16S ? CONV_OUT_F32 : 0;
+            const int last_flags = act_f16_family(e->act) ? CONV_OUT_F32 : 0;
             const bool wfrag = e->act == Act::F16S && e->split_wfrag;
             const int wflag = wfrag ? CONV_W_FRAG : 0;
             auto wptr = [&](const ConvLayer& c) { return wfrag ? c.wf.p : c.w.p; };
             launch_conv3x3_mfma(e->act, L.x0.p, wptr(e->stem), e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
-                                fused_stem ? &stem_in : nullptr, wflag | (d.blocks == 0 ? last_flags : 0));
+                                fused_stem ? &stem_in : nullptr, wflag | (d.blocks == 0 ? last_flags : 0), e->conv_opts);
             for (uint32_t i = 0; i < d.blocks; i++) {
                 s0 = ev(false), s1 = ev(true);
                 launch_conv3x3_mfma(e->act, a, wptr(*e->c1[i]), e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1, nullptr,
-                                    wflag);
+                                    wflag, e->conv_opts);
                 s0 = ev(false), s1 = ev(true);
                 launch_conv3x3_mfma(e->act, t, wptr(*e->c2[i]), e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1, nullptr,
-                                    wflag | (i + 1 == d.blocks ? last_flags : 0));
+                                    wflag | (i + 1 == d.blocks ? last_flags : 0), e->conv_opts);
                 std::swap(a, y);
             }
         }
@@ -829,7 +857,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     if ((uint64_t)cfg->plane_words * 64 < (uint64_t)d.board * d.board || cfg->plane_words > 2)
         return fail(CATTUS_E_INVALID, "plane_words %u cannot hold a %ux%u board", cfg->plane_words, d.board, d.board);
     if (d.planes * cfg->plane_words > 128) return fail(CATTUS_E_UNSUPPORTED, "more than 128 plane words per leaf");
-    if (cfg->dtype != CATTUS_DTYPE_F32 && cfg->dtype != CATTUS_DTYPE_BF16 && cfg->dtype != CATTUS_DTYPE_F16X2)
+    if (cfg->dtype != CATTUS_DTYPE_F32 && cfg->dtype != CATTUS_DTYPE_BF16 && cfg->dtype != CATTUS_DTYPE_F16X2 && cfg->dtype != CATTUS_DTYPE_F16)
         return fail(CATTUS_E_INVALID, "unknown dtype %u", cfg->dtype);
     if (!simple && (size_t)d.phc * d.board * d.board * 8 * 4 > 64 * 1024) return fail(CATTUS_E_UNSUPPORTED, "policy head too wide for the FC kernel");
 
@@ -861,8 +889,8 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
                                               "export HIP_FORCE_DEV_KERNARG=1 before the process initialises HIP";
     }
     const char* wait_mode = getenv("CATTUS_HIP_WAIT");
-    set_conv_cb(getenv("CATTUS_CONV_CB") ? atoi(getenv("CATTUS_CONV_CB")) : 0);
-    set_conv_pbw(getenv("CATTUS_CONV_PBW") ? atoi(getenv("CATTUS_CONV_PBW")) : 0);
+    const char* conv_cb_env = getenv("CATTUS_CONV_CB");
+    const char* conv_pbw_env = getenv("CATTUS_CONV_PBW");
     const char* fused_stem_env = getenv("CATTUS_FUSED_STEM");
     const char* t64_ch_env = getenv("CATTUS_T64_CH");
     const char* t64_ls_env = getenv("CATTUS_T64_LS");
@@ -879,6 +907,8 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->t64_force_ch = t64_ch_env ? atoi(t64_ch_env) : 0;
     e->t64_layer_steps = !(t64_ls_env && atoi(t64_ls_env) == 0);
     e->split_wfrag = !(split_w_env && split_w_env[0] == '0');
+    e->conv_opts.cb = conv_cb_env ? atoi(conv_cb_env) : 0;
+    e->conv_opts.pbw = conv_pbw_env ? atoi(conv_pbw_env) : 0;
     e->hw = d.board * d.board;
     // The MFMA tower covers every board up to 11x11 and any filter count (channels are padded to 64 with zeros);
     // the two 1x1 head convs share one 32-row MFMA tile.  Wider heads take the generic f32 path (one thread
@@ -886,12 +916,22 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     const char* force_generic = getenv("CATTUS_FORCE_GENERIC");
     e->simple = simple;
     e->tuned = !simple && d.vhc + d.phc <= 32 && !(force_generic && force_generic[0] == '1');
-    e->act = simple ? Act::F32 : cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16 : cfg->dtype == CATTUS_DTYPE_F16X2 ? Act::F16S : Act::F32;
+    e->act = simple ? Act::F32
+             : cfg->dtype == CATTUS_DTYPE_BF16 ? Act::BF16
+             : cfg->dtype == CATTUS_DTYPE_F16X2 ? Act::F16S
+             : cfg->dtype == CATTUS_DTYPE_F16 ? Act::F16
+                                              : Act::F32;
     if (!e->tuned && e->act != Act::F32)
-        return fail(CATTUS_E_UNSUPPORTED, "bf16 / f16x2 need the MFMA tower: value + policy head channels <= 32 (got %u + %u)", d.vhc, d.phc);
-    if (e->act == Act::F16S) {
-        // the split tower's stem expands the planes itself (its input has no lo half); no separate plane pack exists for it
-        if (d.planes > 32) return fail(CATTUS_E_UNSUPPORTED, "f16x2 takes at most 32 input planes (got %u)", d.planes);
+        return fail(CATTUS_E_UNSUPPORTED, "bf16 / f16 / f16x2 need the MFMA tower: value + policy head channels <= 32 (got %u + %u)", d.vhc, d.phc);
+    if (act_f16_family(e->act)) {
+        int src = e->d_saturated.alloc(sizeof(unsigned));
+        if (src) return src;
+        HIP_TRY(hipMemset(e->d_saturated.p, 0, sizeof(unsigned)));
+        e->conv_opts.saturated = e->d_saturated.as<unsigned>();
+    }
+    if (act_f16_family(e->act)) {
+        // the f16 towers' stems expand the planes themselves (no separate plane pack exists for them)
+        if (d.planes > 32) return fail(CATTUS_E_UNSUPPORTED, "f16x2 / f16 take at most 32 input planes (got %u)", d.planes);
         e->pack_separately = false;
     }
     e->slots = tower_slots(d.board);
@@ -1078,7 +1118,13 @@ CATTUS_API void cattus_hip_host_free(void* p) {
 
 CATTUS_API int cattus_hip_stats(cattus_eval* e, cattus_stats* out) {
     if (!e || !out) return fail(CATTUS_E_INVALID, "NULL argument");
+    unsigned sat = 0;
+    if (e->d_saturated.p) {  // a 4-byte read of the sticky device counter (batches still in flight may add to it later)
+        HIP_TRY(hipSetDevice(e->device));
+        HIP_TRY(hipMemcpy(&sat, e->d_saturated.p, sizeof sat, hipMemcpyDeviceToHost));
+    }
     std::lock_guard<std::mutex> lk(e->stat_mu);
+    e->stats.saturated = sat;
     *out = e->stats;
     return CATTUS_OK;
 }

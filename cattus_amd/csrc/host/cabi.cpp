@@ -30,7 +30,7 @@ auto dispatch(int game, F&& f) -> decltype(f(TttGame{})) {
     }
 }
 
-SelfPlayConfig to_config(const cattus_sp_config* c) {
+SelfPlayConfig to_config(const cattus_sp_config* c, uint32_t games_num = 0) {
     SelfPlayConfig cfg;
     cfg.mcts.sim_num = c->sim_num;
     cfg.mcts.explore_factor = c->explore_factor;
@@ -53,6 +53,8 @@ SelfPlayConfig to_config(const cattus_sp_config* c) {
     cfg.eval_threads = c->eval_threads ? std::min(c->eval_threads, 256u) : 2;
     cfg.mcts.leaves_in_flight = std::max(1u, std::min(c->leaves_in_flight, 16u));
     cfg.max_game_plies = c->max_game_plies;
+    if (c->game_list) cfg.game_list.assign(c->game_list, c->game_list + games_num);
+    if (c->progress_path) cfg.progress_path = c->progress_path;
     return cfg;
 }
 
@@ -243,7 +245,7 @@ SP_API int cattus_sp_run(int game, const cattus_sp_config* c, cattus_net_eval_fn
         const bool same = net2 == nullptr;
         const NetHandle h1{net1, ctx1, c->legal_net1};
         const NetHandle h2 = same ? h1 : NetHandle{net2, ctx2, c->legal_net2};
-        SelfPlayRunner<G> runner(to_config(c), h1, h2, same);
+        SelfPlayRunner<G> runner(to_config(c, games_num), h1, h2, same);
         auto res = std::make_unique<cattus_sp_result>();
         SelfPlayResult r;
         rc = runner.generate_data(games_num, out_dir1 ? out_dir1 : "", out_dir2 ? out_dir2 : "", &res->records, r);

@@ -332,6 +332,10 @@ struct SelfPlayConfig {
     // this process plays global game indices first_game + k*game_stride, k = 0..games_num-1
     uint32_t first_game = 0, game_stride = 1;
     uint32_t max_game_plies = 0;  // > 0 (not in the reference): adjudicate a draw after this many plies
+    // failure containment (include/cattus_selfplay.h): explicit game indices of a re-queue; a progress file that gets one
+    // line per finished game
+    std::vector<uint32_t> game_list;
+    std::string progress_path;
     // optional allocator for the batch buffers handed to the network callback (page-locked memory
     // from cattus_hip_host_alloc lets the evaluator DMA straight into them)
     void* (*host_alloc)(size_t) = nullptr;
@@ -368,10 +372,25 @@ class SelfPlayRunner {
     // the out dirs are non-empty).  games_num must be even (self_play.rs:100).
     int generate_data(uint32_t games_num, const std::string& out_dir1, const std::string& out_dir2,
                       std::vector<Record>* records, SelfPlayResult& res) {
-        if (games_num % 2 != 0) {
+        if (games_num % 2 != 0 && cfg_.game_list.empty()) {  // a re-queued list is what was left of an even job
             error_ = "Games num should be a multiple of 2";
             return -1;
         }
+        if (!cfg_.game_list.empty() && cfg_.game_list.size() != games_num) {
+            error_ = "game_list must hold games_num entries";
+            return -1;
+        }
+        progress_ = nullptr;
+        if (!cfg_.progress_path.empty() && !(progress_ = fopen(cfg_.progress_path.c_str(), "a"))) {
+            error_ = "cannot open progress file " + cfg_.progress_path;
+            return -4;
+        }
+        struct ProgressCloser {
+            FILE*& f;
+            ~ProgressCloser() {
+                if (f) fclose(f), f = nullptr;
+            }
+        } progress_closer{progress_};
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t nslots = cfg_.concurrent_games ? cfg_.concurrent_games : std::max(cfg_.threads, cfg_.batch_size);
         nslots = std::max(1u, std::min(nslots, std::max(games_num, 1u)));
@@ -647,7 +666,7 @@ class SelfPlayRunner {
                         s.state = Slot::DONE;
                         return;
                     }
-                    s.game_idx = cfg_.first_game + local * cfg_.game_stride;
+                    s.game_idx = cfg_.game_list.empty() ? cfg_.first_game + local * cfg_.game_stride : cfg_.game_list[local];
                     s.players_switch = s.game_idx % 2 == 1;
                     // the random streams belong to the game, not to the slot that happens to play it: a game
                     // is then the same whatever the schedule, the slot count or the sharding over processes
@@ -768,11 +787,17 @@ class SelfPlayRunner {
         }
         res.positions += s.pairs.size();
         if (adjudicated) res.adjudicated++;
+        int tally = 0;
         if (winner == 0) res.d++;
         else {
             int8_t w = winner;
             if (s.players_switch) w = (int8_t)-w;
             (w > 0 ? res.w1 : res.w2)++;
+            tally = w > 0 ? 1 : 2;
+        }
+        if (progress_) {  // behind the game's records: a line here means the game is complete on disk
+            fprintf(progress_, "%u %zu %d %d\n", s.game_idx, s.pairs.size(), tally, adjudicated ? 1 : 0);
+            fflush(progress_);
         }
     }
 
@@ -781,6 +806,7 @@ class SelfPlayRunner {
     NetValueFunction<G> vf1_, vf2_;
     bool same_model_;
     std::string error_;
+    FILE* progress_ = nullptr;  // guarded by generate_data's out_mu
 };
 
 }  // namespace cattus

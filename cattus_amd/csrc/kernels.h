@@ -10,15 +10,21 @@ inline uint32_t tower_slots(uint32_t S) { return S <= 8 ? 64u : 128u; }
 constexpr int ROWS_PER_WG = 256; // tower rows per workgroup of the conv kernel: 4 boards of 64 slots, 2 of 128
 constexpr int COUT_PER_WG = 64;  // output channels per workgroup of the tower conv kernel
 
-// Activation element of the tuned tower: 2-byte bf16, 4-byte f32, or a pair of f16 values (hi, lo) of 2 + 2 bytes
-// (the split-precision tower: 128 bytes of a row are [hi of 32 channels | lo of the same 32]).
-enum class Act : int { F32 = 0, BF16 = 1, F16S = 2 };
+// Activation element of the tuned tower: 2-byte bf16, 4-byte f32, a pair of f16 values (hi, lo) of 2 + 2 bytes
+// (the split-precision tower: 128 bytes of a row are [hi of 32 channels | lo of the same 32]), or a single 2-byte f16
+// (the single-term f16 tower: the bf16 kernel's layout and MFMA count with 11 significant bits instead of 8).
+enum class Act : int { F32 = 0, BF16 = 1, F16S = 2, F16 = 3 };
 
-inline int act_bytes(Act a) { return a == Act::BF16 ? 2 : 4; }  // bytes of one activation in HBM
+inline bool act_two_bytes(Act a) { return a == Act::BF16 || a == Act::F16; }
+inline int act_bytes(Act a) { return act_two_bytes(a) ? 2 : 4; }  // bytes of one activation in HBM
 // Input channels consumed per pipeline stage: one 128-byte LDS row.
-inline int act_kc(Act a) { return a == Act::BF16 ? 64 : 32; }
-// Element type of the head kernels (K3-K5) for a tower of type `a`: the split tower's heads run in exact f32.
+inline int act_kc(Act a) { return act_two_bytes(a) ? 64 : 32; }
+// Element type of the head kernels (K3-K5) for a tower of type `a`: the f16 towers' heads run in exact f32 (their last
+// layer writes plain f32 rows).
 inline Act head_act(Act a) { return a == Act::BF16 ? Act::BF16 : Act::F32; }
+// The f16 towers: weights pre-scaled per output channel by a power of two, the bias buffer carries the inverse scales,
+// activations saturate at 65504 (counted), the last layer writes f32 rows.
+inline bool act_f16_family(Act a) { return a == Act::F16S || a == Act::F16; }
 
 // Sets the > 64 KiB dynamic-LDS attribute of every tower kernel variant on the current device; called once per device
 // from cattus_hip_create before the first launch.
@@ -45,7 +51,9 @@ struct StemInput {
 // Act::F16S (split precision): rows of in / res / out and of w are f16 pairs interleaved in groups of 32 channels,
 // [hi of channels 32g .. 32g+31 | lo of the same 32] per 128 bytes; w is pre-scaled per output channel by a power of
 // two, bias is [cout biases | cout inverse scales]; cin counts channels (pairs).
-// flags & CONV_OUT_F32 (F16S only): out is written as plain f32 [row][cout] (last tower layer, read by the f32 head kernels).
+// Act::F16 (single-term f16): rows of f16 values in the bf16 tower's layout, w [9][cout][cin] f16 pre-scaled as above, bias
+// [cout biases | cout inverse scales].
+// flags & CONV_OUT_F32 (F16S / F16 only): out is written as plain f32 [row][cout] (last tower layer, read by the f32 head kernels).
 // flags & CONV_W_FRAG (F16S only): w is in MFMA fragment order, [cout / 32][stage][hi | lo][lane][8 f16] with
 // stage = ((chunk * 3 + dy) * 3 + dx) * 2 + k-half (split_frag_index below): the kernel that keeps the weights in a register
 // ring instead of LDS.  Non-stem layers then need cin >= 64.
@@ -56,19 +64,22 @@ inline size_t split_frag_index(uint32_t t, uint32_t co, uint32_t ci, uint32_t pa
     const uint32_t stage = ((ch * 3 + t / 3) * 3 + t % 3) * 2 + k, lane = h * 32 + (co & 31);
     return ((((size_t)(co >> 5) * nst + stage) * 2 + part) * 64 + lane) * 8 + e;
 }
+// Per-evaluator launch options (they used to be process-wide switches: a second evaluator must not re-tile the first).
+struct ConvOpts {
+    int cb = 0;   // forces the conv kernel's tile: 1 = 256 rows x 32 couts, 2 = 256 rows x 64 couts; 0 = chosen by grid size
+    int pbw = 0;  // 2: never / 1: whenever the tile is 32 couts -- the 128-row workgroup; 0 = chosen by grid size
+    // F16S / F16: device counter of activation values that were clamped to 65504 (atomic add on the clamp path only);
+    // must be non-null for those towers
+    unsigned* saturated = nullptr;
+};
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st,
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const StemInput* stem = nullptr,
-                         int flags = 0);
+                         int flags = 0, const ConvOpts& opts = ConvOpts());
 
 // Diagnostic: one launch of nothing but back-to-back MFMAs of the tower's kind (F16S: f16, BF16, F32: 32x32x2 f32), four
 // waves on each of `cus` workgroups, iters x 4 MFMAs per wave; `out` holds cus * 256 floats.  Returns the launch's FLOPs.
 double launch_mfma_sustain(Act act, int cus, int iters, float* out, hipStream_t st);
-
-// Forces the conv kernel's tile (1: 256 rows x 32 couts, 2: 256 rows x 64 couts; 0: chosen by grid size).
-void set_conv_cb(int v);
-// 2: the f16x2 conv never uses its 128-row workgroup (otherwise chosen for grids of <= 128 32-cout workgroups).
-void set_conv_pbw(int v);
 
 // ---- K1 resident: whole tower of a network with <= 64 (padded) filters in one launch, bf16 (see kernels.hip) ----
 struct Tower64Layer {

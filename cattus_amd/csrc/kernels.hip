@@ -232,6 +232,19 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 #define STAMP_FLUSH(wave)
 #endif
 
+// The f16 towers store activations as f16 and clamp them at 65504 instead of letting them overflow to infinity.  A clamped
+// value is a wrong value: it is counted (atomic add on the clamp path only -- a network inside the f16 range never gets
+// here) into the evaluator's sticky counter, which cattus_hip_stats reports as `saturated`.
+__device__ __forceinline__ void note_saturation(const float (&y)[8], bool valid, unsigned* sat) {
+    const float m = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+    if (valid && m > 65504.0f) {
+        unsigned n = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) n += y[j] > 65504.0f ? 1u : 0u;
+        atomicAdd(sat, n);
+    }
+}
+
 __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
 }
@@ -286,8 +299,12 @@ struct StemPlanes<true> {
 template <typename T, bool HAS_RES, bool BIG, bool STEM = false, int CB = 2, int PBW = 2>
 __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     conv3x3_mfma_v2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
-                           const T* __restrict__ res, T* __restrict__ out, int cin, int cout, int S, StemPlanes<STEM> sp) {
+                           const T* __restrict__ res, T* __restrict__ out, unsigned* __restrict__ sat, int cin, int cout, int S,
+                           int flags, StemPlanes<STEM> sp) {
     static_assert(NLOAD == 4, "the stem expansion, the 32-cout tile and the piece counts below assume four loader waves");
+    // single-term f16 tower: weights pre-scaled per output channel (`bias` = [cout biases | cout inverse scales]), activations
+    // clamped at 65504 and counted in `sat`, flags & CONV_OUT_F32 = plain f32 output rows; `sat` / `flags` are not read otherwise
+    constexpr bool F16T = std::is_same<T, _Float16>::value;
     constexpr int KC = 128 / (int)sizeof(T);
     constexpr int CPW = 32 * CB;          // output channels of this workgroup
     constexpr int WPLC = WPL * CB / 2;    // weight pieces per loader wave and step
@@ -472,14 +489,23 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     // Epilogue operands that depend on nothing computed here are requested now, so their latency hides
     // under the main loop: the folded-BN bias of this lane's 8 cout quads, and (2-byte activations only,
     // for register budget) the skip-connection rows in the epilogue's (pixel row, 8 couts) layout.
-    f32x4 biasv[CB][4];
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
     // epilogue store layout: a pixel row of the tile is CPW couts = LPR lanes x 8 couts; 64 / LPR rows per trip
     constexpr int LPR = 4 * CB, RPT = 64 / LPR, EIT = PXW / RPT;
     const int prow = lane / LPR, cg = lane % LPR;
+    f32x4 biasv[CB][4];   // bf16 / f32: added in the accumulator layout, before the transpose
+    f32x4 bias8[2], ds8[2];  // f16: bias and inverse weight scale of the 8 couts the lane owns AFTER the transpose
+    if constexpr (!F16T) {
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) biasv[cb][g] = *reinterpret_cast<const f32x4*>(bias + cout0 + cb * 32 + g * 8 + h * 4);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            bias8[q] = *reinterpret_cast<const f32x4*>(bias + cout0 + cg * 8 + q * 4);
+            ds8[q] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cg * 8 + q * 4);
+        }
+    }
     constexpr bool RES_EARLY = HAS_RES && sizeof(T) == 2;
     T resv[EIT][8];
     if (RES_EARLY) {
@@ -588,10 +614,15 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             for (int pb = 0; pb < PBW; pb++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const f32x4 bv = biasv[cb][g];
                     f32x4 v;
+                    if constexpr (F16T) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
+                        for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i];
+                    } else {
+                        const f32x4 bv = biasv[cb][g];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) v[i] = acc[cb][pb][g * 4 + i] + bv[i];
+                    }
                     const int slot = (cb * 8 + g * 2 + h) ^ (r & 7);
                     *reinterpret_cast<f32x4*>(smem + stage_row(pb * 32 + r) + slot * 16) = v;
                 }
@@ -603,17 +634,41 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
             const f32x4 hi = *reinterpret_cast<const f32x4*>(rowp + (((2 * cg + 1) ^ (px & 7)) << 4));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const size_t off = (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
+            if constexpr (F16T) {  // the accumulator carries the weights' power-of-two scale: times its inverse is exact
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = __builtin_fmaf(v[j], ds8[j >> 2][j & 3], bias8[j >> 2][j & 3]);
+            }
             if (HAS_RES) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = v[j] + (float)resv[i][j];
             }
             const bool valid = pslot0 + px < S * S;
             T ov[8];
+            if constexpr (F16T) {
+                float y[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                float y = v[j] > 0.0f ? v[j] : 0.0f;
-                if (!valid) y = 0.0f;
-                ov[j] = (T)y;
+                for (int j = 0; j < 8; j++) y[j] = valid && v[j] > 0.0f ? v[j] : 0.0f;
+                if (flags & CONV_OUT_F32) {  // the tower's last layer: plain f32 rows for the head kernels
+                    float* of = reinterpret_cast<float*>(out) + off;
+                    if constexpr (CB == 1) {
+                        reinterpret_cast<f32x4*>(of)[0] = *reinterpret_cast<f32x4*>(y);
+                        reinterpret_cast<f32x4*>(of)[1] = *reinterpret_cast<f32x4*>(y + 4);
+                    } else {
+                        __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y), reinterpret_cast<f32x4*>(of));
+                        __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y + 4), reinterpret_cast<f32x4*>(of) + 1);
+                    }
+                    continue;
+                }
+                note_saturation(y, valid, sat);
+#pragma unroll
+                for (int j = 0; j < 8; j++) ov[j] = (T)(y[j] < 65504.0f ? y[j] : 65504.0f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float y = v[j] > 0.0f ? v[j] : 0.0f;
+                    if (!valid) y = 0.0f;
+                    ov[j] = (T)y;
+                }
             }
             // non-temporal: the line leaves for memory early instead of at the kernel's end (plain stores: launch 18.35 ->
             // 18.7 us, one batch at a time unchanged, two batches in flight +3 %, self-play +0.8 %; profiles/r02_experiments.txt)
@@ -644,11 +699,6 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long));
 }
 #endif
-
-static std::atomic<int> g_conv_cb{0};  // 0: by grid size; 1 / 2: 32 / 64 couts per workgroup (CATTUS_CONV_CB, A/B runs and the equality test)
-void set_conv_cb(int v) { g_conv_cb = (v == 1 || v == 2) ? v : 0; }
-static std::atomic<int> g_conv_pbw{0};  // 2: never / 1: whenever the tile is 32 couts -- the 128-row workgroup of the conv kernels (A/B, tests)
-void set_conv_pbw(int v) { g_conv_pbw = (v == 1 || v == 2) ? v : 0; }
 
 
 // ------------------------------------------------------------------------------------------
@@ -688,8 +738,8 @@ constexpr int SP_WPL = 7, SP_APL = 5;                   // pieces per loader wav
 template <bool HAS_RES, bool BIG, bool STEM, int CB>
 __global__ void __launch_bounds__(512, 2)
     conv3x3_split_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ w, const float* __restrict__ bias,
-                         const _Float16* __restrict__ res, _Float16* __restrict__ out, int cin, int cout, int S, int flags,
-                         StemPlanes<STEM> sp) {
+                         const _Float16* __restrict__ res, _Float16* __restrict__ out, unsigned* __restrict__ sat, int cin, int cout,
+                         int S, int flags, StemPlanes<STEM> sp) {
     typedef _Float16 T;
     typedef Mfma<T>::frag frag;
     constexpr int KC = 32;        // channels (pairs) per 128-byte chunk
@@ -992,6 +1042,7 @@ __global__ void __launch_bounds__(512, 2)
             } else {
                 const size_t off = (wrow0 + px) * orow + ocol;
                 T hi[8], lo[8];
+                note_saturation(y, true, sat);  // rows past the board are zero already
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const float yc = y[j] < 65504.0f ? y[j] : 65504.0f;  // saturate instead of overflowing to infinity
@@ -1046,8 +1097,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <bool HAS_RES, bool BIG, bool STEM, int CB, int PBW = 2>
 __global__ void __launch_bounds__(512, 2)
     conv3x3_splitw_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wf, const float* __restrict__ bias,
-                          const _Float16* __restrict__ res, _Float16* __restrict__ out, int cin, int cout, int S, int flags,
-                          StemPlanes<STEM> sp) {
+                          const _Float16* __restrict__ res, _Float16* __restrict__ out, unsigned* __restrict__ sat, int cin, int cout,
+                          int S, int flags, StemPlanes<STEM> sp) {
     typedef _Float16 T;
     typedef Mfma<T>::frag frag;
     constexpr int KC = 32;        // channels (pairs) per 128-byte chunk
@@ -1393,6 +1444,7 @@ __global__ void __launch_bounds__(512, 2)
             } else {
                 const size_t off = (wrow0 + px) * orow + ocol;
                 T hi[8], lo[8];
+                note_saturation(y, valid, sat);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const float yc = y[j] < 65504.0f ? y[j] : 65504.0f;
@@ -1484,12 +1536,17 @@ static hipError_t split_attrs() {
 
 void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bias, const void* res, void* out,
                          uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S, hipStream_t st, hipEvent_t ev_start,
-                         hipEvent_t ev_stop, const StemInput* stem, int flags) {
+                         hipEvent_t ev_stop, const StemInput* stem, int flags, const ConvOpts& opts) {
     const uint32_t slots = tower_slots(S);
     // 256 rows x 64 couts per workgroup; 256 rows x 32 couts while that grid would leave half of the CUs empty
     const uint32_t full_grid = (bpad * slots / ROWS_PER_WG) * (cout / COUT_PER_WG);
     int cb = full_grid <= 128 ? 1 : 2;
-    if (const int forced = g_conv_cb.load(std::memory_order_relaxed)) cb = forced;
+    if (opts.cb == 1 || opts.cb == 2) cb = opts.cb;
+    unsigned* const sat = opts.saturated;
+    if (act_f16_family(act) && !sat) {
+        fprintf(stderr, "cattus: launch_conv3x3_mfma: the f16 towers need ConvOpts::saturated\n");
+        abort();
+    }
     const dim3 grid(full_grid * (cb == 1 ? 2 : 1));
     if (act == Act::F16S) {
         typedef _Float16 H;
@@ -1499,22 +1556,22 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
             abort();
         }
         // 128 rows x 32 couts per workgroup while even the 32-cout grid would leave half of the CUs empty (register ring only)
-        const int pbw_forced = g_conv_pbw.load(std::memory_order_relaxed);
+        const int pbw_forced = opts.pbw;
         const bool half_rows = wfrag && cb == 1 && ((grid.x <= 128 && pbw_forced != 2) || pbw_forced == 1);
         const dim3 grid_half(grid.x * 2);
 #define CATTUS_LAUNCH_SPLIT(R, BIG, STEMV, CBV, SPV)                                                                                   \
     do {                                                                                                                               \
         if (wfrag && half_rows && CBV == 1)                                                                                            \
             hipExtLaunchKernelGGL((conv3x3_splitw_kernel<R, BIG, STEMV, 1, 1>), grid_half, dim3(512), sw_lds_total(1, 1), st, ev_start, \
-                                  ev_stop, 0, (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S,   \
+                                  ev_stop, 0, (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, sat, (int)cin, (int)cout, (int)S,   \
                                   flags, SPV);                                                                                         \
         else if (wfrag)                                                                                                                \
             hipExtLaunchKernelGGL((conv3x3_splitw_kernel<R, BIG, STEMV, CBV>), grid, dim3(512), sw_lds_total(CBV), st, ev_start,       \
-                                  ev_stop, 0, (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S,   \
+                                  ev_stop, 0, (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, sat, (int)cin, (int)cout, (int)S,   \
                                   flags, SPV);                                                                                         \
         else                                                                                                                           \
             hipExtLaunchKernelGGL((conv3x3_split_kernel<R, BIG, STEMV, CBV>), grid, dim3(512), SP_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                                  (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, (int)cin, (int)cout, (int)S, flags, SPV);   \
+                                  (const H*)in, (const H*)w, bias, (const H*)res, (H*)out, sat, (int)cin, (int)cout, (int)S, flags, SPV);   \
     } while (0)
 #define CATTUS_LAUNCH_SPLIT_CB(CBV)                                                                       \
     do {                                                                                                  \
@@ -1537,27 +1594,27 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
         return;
     }
     // 128 rows x 32 couts per workgroup while even the 32-cout grid would leave half of the CUs empty (as the split conv does)
-    const int pbw_forced2 = g_conv_pbw.load(std::memory_order_relaxed);
+    const int pbw_forced2 = opts.pbw;
     const bool half_rows2 = cb == 1 && ((grid.x <= 128 && pbw_forced2 != 2) || pbw_forced2 == 1);
     const dim3 grid_half2(grid.x * 2);
 #define CATTUS_LAUNCH_CONV2(T, R, BIG, CBV)                                                               \
     do {                                                                                                  \
         if (half_rows2 && CBV == 1)                                                                       \
             hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, 1, 1>), grid_half2, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                                  (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{}); \
+                                  (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, sat, (int)cin, (int)cout, (int)S, flags, StemPlanes<false>{}); \
         else                                                                                              \
             hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, R, BIG, false, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                                  (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, (int)cin, (int)cout, (int)S, StemPlanes<false>{}); \
+                                  (const T*)in, (const T*)w, bias, (const T*)res, (T*)out, sat, (int)cin, (int)cout, (int)S, flags, StemPlanes<false>{}); \
     } while (0)
 #define CATTUS_LAUNCH_STEM(T, BIG, CBV)                                                                   \
     do {                                                                                                  \
         if (half_rows2 && CBV == 1)                                                                       \
             hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, 1, 1>), grid_half2, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                                  (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
+                                  (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, sat, (int)cin, (int)cout, (int)S, flags, \
                                   StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64});           \
         else                                                                                              \
             hipExtLaunchKernelGGL((conv3x3_mfma_v2_kernel<T, false, BIG, true, CBV>), grid, dim3(256 + 64 * NLOAD), V2_LDS_TOTAL, st, ev_start, ev_stop, 0, \
-                                  (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, (int)cin, (int)cout, (int)S, \
+                                  (const T*)nullptr, (const T*)w, bias, (const T*)nullptr, (T*)out, sat, (int)cin, (int)cout, (int)S, flags, \
                                   StemPlanes<true>{stem->planes, stem->n, stem->C, stem->w64});           \
     } while (0)
 #define CATTUS_LAUNCH_CONV2_CB(T, CBV)                            \
@@ -1579,6 +1636,7 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
         else CATTUS_LAUNCH_CONV2_CB(T, 2);        \
     } while (0)
     if (act == Act::BF16) CATTUS_LAUNCH_CONV2_T(__bf16);
+    else if (act == Act::F16) CATTUS_LAUNCH_CONV2_T(_Float16);
     else CATTUS_LAUNCH_CONV2_T(float);
 #undef CATTUS_LAUNCH_CONV2_T
 #undef CATTUS_LAUNCH_CONV2_CB
@@ -2058,6 +2116,8 @@ void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, bool layer_s
 hipError_t prepare_device() {
     hipError_t err = conv_attrs_for<__bf16>();
     hipError_t e2 = conv_attrs_for<float>();
+    if (err == hipSuccess) err = e2;
+    e2 = conv_attrs_for<_Float16>();
     if (err == hipSuccess) err = e2;
     e2 = split_attrs();
     if (err == hipSuccess) err = e2;
@@ -2673,7 +2733,7 @@ __global__ void __launch_bounds__(256) mfma_sustain_kernel(int iters, float* __r
 // One launch: `cus` workgroups of four waves, iters x 4 MFMAs per wave; returns the FLOPs of the launch.
 double launch_mfma_sustain(Act act, int cus, int iters, float* out, hipStream_t st) {
     const dim3 grid(cus), block(256);
-    if (act == Act::F16S) hipLaunchKernelGGL(mfma_sustain_kernel<0>, grid, block, 0, st, iters, out);
+    if (act_f16_family(act)) hipLaunchKernelGGL(mfma_sustain_kernel<0>, grid, block, 0, st, iters, out);
     else if (act == Act::BF16) hipLaunchKernelGGL(mfma_sustain_kernel<1>, grid, block, 0, st, iters, out);
     else hipLaunchKernelGGL(mfma_sustain_kernel<2>, grid, block, 0, st, iters, out);
     const double flop_per_mfma = act == Act::F32 ? 2.0 * 32 * 32 * 2 : 2.0 * 32 * 32 * 16;

@@ -4,8 +4,10 @@ Games are independent (training/self-play/src/self_play.rs:109,184), so each ran
 GPU) plays the global game indices ``g = rank (mod world)`` with its own evaluator; there is no
 collective on the evaluation path.  The reference "pools" records by having every thread write one
 file per position into a shared directory (self_play.rs:60); across GPUs the fixed-size records are
-pooled once per self-play round with an all-gather (counts first, then zero-padded payload), and the
-win counters with an all-reduce.  With backend "nccl" this is RCCL over xGMI; tests use "gloo".
+pooled once per self-play round on rank 0 (counts all-gathered first, then one gather of the zero-padded payloads),
+and the win counters with an all-reduce.  With backend "nccl" this is RCCL over xGMI; tests use "gloo".
+Failure containment (a rank that dies; cattus_amd/supervisor.py): every rank also writes its records to the out
+directories and a progress line per finished game BEFORE any collective, so a hung or failed collective loses nothing.
 """
 
 from __future__ import annotations
@@ -21,39 +23,44 @@ def shard_games(games_num: int, rank: int, world: int) -> tuple[int, int, int]:
     return rank, world, games_num // world
 
 
-def pool_records(record_bytes: np.ndarray, record_meta: np.ndarray, device=None):
-    """All-gather the records of every rank; returns (bytes [N, R] uint8, meta [N, 3] uint32) sorted
-    by (game, ply), identical on all ranks."""
+def pool_records(record_bytes: np.ndarray, record_meta: np.ndarray, device=None, dst: int | None = 0):
+    """Pool the records of every rank on rank `dst` (default 0: the one that writes / hands them to the trainer); returns
+    (bytes [N, R] uint8, meta [N, 3] uint32) sorted by (game, ply) there and (None, None) on the other ranks.  Counts travel
+    first (all-gather of one int64), then each rank's payload zero-padded to the largest shard in ONE gather: only `dst` holds
+    world x largest shard, and only `dst` copies anything back to the host.  dst=None: every rank gets the pooled set
+    (all-gather; world x the memory and the host copies on every rank -- tests and small runs)."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     rec = torch.from_numpy(np.ascontiguousarray(record_bytes, dtype=np.uint8))
-    meta = torch.from_numpy(np.ascontiguousarray(record_meta, dtype=np.uint32).view(np.int32))
+    meta = torch.from_numpy(np.ascontiguousarray(record_meta, dtype=np.uint32).view(np.uint8).reshape(len(record_meta), 12))
     dev = torch.device(device) if device is not None else torch.device("cpu")
-    n_local = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    counts = [int(c.item()) for c in counts]
-    nmax, r = max(counts + [1]), rec.shape[1] if rec.ndim == 2 else 0
-    r_t = torch.tensor([r], dtype=torch.int64, device=dev)
-    dist.all_reduce(r_t, op=dist.ReduceOp.MAX)
-    r = int(r_t.item())
-    pad_rec = torch.zeros((nmax, r), dtype=torch.uint8, device=dev)
-    pad_meta = torch.zeros((nmax, 3), dtype=torch.int32, device=dev)
+    # counts and record width of every rank (a rank that played nothing has width 0)
+    mine = torch.tensor([rec.shape[0], rec.shape[1] if rec.ndim == 2 else 0], dtype=torch.int64, device=dev)
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    counts = [int(c[0].item()) for c in everyone]
+    r = max(int(c[1].item()) for c in everyone)
+    nmax = max(counts + [1])
+    # one payload per rank: [nmax][r record bytes | 12 meta bytes]
+    pad = torch.zeros((nmax, r + 12), dtype=torch.uint8, device=dev)
     if rec.shape[0]:
-        pad_rec[: rec.shape[0]] = rec.to(dev)
-        pad_meta[: rec.shape[0]] = meta.to(dev)
-    all_rec = [torch.empty_like(pad_rec) for _ in range(world)]
-    all_meta = [torch.empty_like(pad_meta) for _ in range(world)]
-    dist.all_gather(all_rec, pad_rec)
-    dist.all_gather(all_meta, pad_meta)
-    recs = np.concatenate([t[:c].cpu().numpy() for t, c in zip(all_rec, counts)]) if sum(counts) else np.zeros((0, r), np.uint8)
-    metas = (
-        np.concatenate([t[:c].cpu().numpy() for t, c in zip(all_meta, counts)]).view(np.uint32)
-        if sum(counts)
-        else np.zeros((0, 3), np.uint32)
-    )
+        pad[: rec.shape[0], :r] = rec.to(dev)
+        pad[: rec.shape[0], r:] = meta.to(dev)
+    if dst is None:
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+    else:
+        parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, parts, dst=dst)
+        if rank != dst:
+            return None, None
+    if not sum(counts):
+        return np.zeros((0, r), np.uint8), np.zeros((0, 3), np.uint32)
+    flat = np.concatenate([t[:c].cpu().numpy() for t, c in zip(parts, counts) if c])
+    recs = np.ascontiguousarray(flat[:, :r])
+    metas = np.ascontiguousarray(flat[:, r:]).view(np.uint32).reshape(-1, 3)
     order = np.lexsort((metas[:, 1], metas[:, 0]))
     return recs[order], metas[order]
 

@@ -22,9 +22,9 @@ _PKG = Path(__file__).resolve().parent
 # CATTUS_HIP_LIB selects another build of the same ABI (e.g. the stamped diagnostic build)
 LIB_PATH = Path(os.environ.get("CATTUS_HIP_LIB", _PKG / "libcattus_hip.so"))
 
-DTYPE_F32, DTYPE_BF16, DTYPE_F16X2 = 0, 1, 2
-# "f16x2": the split-precision tower (pairs of f16 values, 22 significant bits; include/cattus_hip.h)
-_DTYPES = {"f32": DTYPE_F32, "bf16": DTYPE_BF16, "f16x2": DTYPE_F16X2}
+DTYPE_F32, DTYPE_BF16, DTYPE_F16X2, DTYPE_F16 = 0, 1, 2, 3
+# "f16x2": the split-precision tower (pairs of f16 values, 22 significant bits; include/cattus_hip.h); "f16": single-term f16
+_DTYPES = {"f32": DTYPE_F32, "bf16": DTYPE_BF16, "f16x2": DTYPE_F16X2, "f16": DTYPE_F16}
 
 # every symbol include/cattus_hip.h declares
 ABI_SYMBOLS = [
@@ -77,6 +77,7 @@ class Stats(C.Structure):
         ("full_batches", C.c_uint64),
         ("run_seconds_ema", C.c_double),
         ("run_seconds_total", C.c_double),
+        ("saturated", C.c_uint64),
     ]
 
 

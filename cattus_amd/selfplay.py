@@ -85,6 +85,8 @@ class SpConfig(C.Structure):
         ("eval_threads", C.c_uint32),
         ("leaves_in_flight", C.c_uint32),
         ("max_game_plies", C.c_uint32),
+        ("game_list", C.POINTER(C.c_uint32)),
+        ("progress_path", C.c_char_p),
     ]
 
 
@@ -195,6 +197,8 @@ def make_config(
     eval_threads: int = 0,
     leaves_in_flight: int = 1,
     max_game_plies: int = 0,
+    game_list=None,
+    progress_path=None,
 ) -> SpConfig:
     c = SpConfig()
     c.struct_size = C.sizeof(SpConfig)
@@ -210,6 +214,12 @@ def make_config(
     c.eval_threads = eval_threads  # 0 = the driver's default (2 batches in flight)
     c.max_game_plies = max_game_plies  # > 0: adjudicate a draw after that many plies (bounded samples; not in the reference)
     c.leaves_in_flight = leaves_in_flight  # > 1: several leaves per tree at the network (virtual loss), not in the reference
+    # failure containment (include/cattus_selfplay.h): explicit global game indices (a re-queue) and the progress file
+    if game_list is not None:
+        c._game_list = np.ascontiguousarray(list(game_list), dtype=np.uint32)  # kept alive by the struct object
+        c.game_list = c._game_list.ctypes.data_as(C.POINTER(C.c_uint32))
+    if progress_path is not None:
+        c.progress_path = os.fsencode(str(progress_path))
     return c
 
 
@@ -354,6 +364,8 @@ def run_self_play(game: str, cfg: SpConfig, net1: Net, net2: Net | None, games_n
         cfg.host_alloc, cfg.host_free = net1.host_alloc, net1.host_free
     cfg.legal_net1 = net1.legal_addr
     cfg.legal_net2 = net2.legal_addr if net2 is not None else None
+    if getattr(cfg, "_game_list", None) is not None and len(cfg._game_list) != games_num:
+        raise ValueError(f"game_list holds {len(cfg._game_list)} games, games_num is {games_num}")
     res = C.c_void_p()
     rc = L.cattus_sp_run(
         GAMES[game], C.byref(cfg), net1.fn_addr, net1.ctx, net2.fn_addr if net2 else None, net2.ctx if net2 else None,

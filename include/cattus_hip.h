@@ -45,6 +45,10 @@ typedef enum cattus_dtype {
      * float64 run of the network is that of an f32 runtime (the reference's cross-runtime tolerance,
      * training/tests/test_net_output.py:28-33), at about a third of the bf16 tower's rate. */
     CATTUS_DTYPE_F16X2 = 2,
+    /* Single-term f16: f16 operands and activations (11 significant bits; weights pre-scaled per output channel by a power
+     * of two), f32 accumulation, f32 heads.  A throughput mode like bf16 -- same MFMA count and kernel -- with three more
+     * significand bits; outside the reference's cross-runtime tolerance (DESIGN.md section 4 for what it does to a search). */
+    CATTUS_DTYPE_F16 = 3,
 } cattus_dtype;
 
 /* Replaces the reference's InferenceConfig + batch_size (engine/src/net/model.rs:17-25,
@@ -64,6 +68,10 @@ typedef struct cattus_stats {
     uint64_t full_batches;  /* batches that ran with n == max_batch */
     double run_seconds_ema; /* == reference metric model.run_duration (EMA 0.99, util/metric.rs:16-19) */
     double run_seconds_total;
+    /* f16x2 / f16 towers: activation values that exceeded the f16 range (65504) and were clamped, since the evaluator was
+     * created (sticky).  0 for every network inside the range; > 0 means outputs of this evaluator are NOT the network's:
+     * use dtype f32 for that network (a BatchNorm scale of 1e5 does it; one of 200 does not). */
+    uint64_t saturated;
 } cattus_stats;
 
 /* Network shape as stored in the weight blob header (cattus_amd/weights.py).  filters == 0 (with blocks = vhc = phc = 0) is

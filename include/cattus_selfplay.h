@@ -71,6 +71,16 @@ typedef struct cattus_sp_config {
      * after k plies is adjudicated a draw there and its records are written as such; for bounded
      * benchmark samples of long games (summary field `adjudicated` counts them) */
     uint32_t max_game_plies;
+    /* Failure containment across processes (the reference leaves a dead worker undetected: the TODO at
+     * training/self-play/src/self_play.rs:128).  Both optional (NULL):
+     * game_list: play exactly these global game indices (games_num entries, any parity) instead of
+     *   first_game + k*game_stride -- a supervisor re-queues the unfinished games of a process that died on a fresh one;
+     *   a game is a function of (seed, game index, networks), so its records come out the same wherever it is played.
+     * progress_path: after ALL records of a game have been written, one line
+     *   "<game_idx> <plies> <tally> <adjudicated>\n" (tally 0 draw, 1 player1_wins, 2 player2_wins -- the counter the game
+     *   went to) is appended to this file and flushed: what survives of a process that dies later. */
+    const uint32_t* game_list;
+    const char* progress_path;
 } cattus_sp_config;
 
 typedef struct cattus_sp_summary {

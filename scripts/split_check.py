@@ -25,7 +25,7 @@ for name in golden_names():
     row = {}
     p64, v64 = z["policy_f64"], z["value_f64"]
     row["reference_f32"] = dict(dp=float(np.abs(z["policy"] - p64).max()), dv=float(np.abs(z["value"] - v64).max()))
-    for dtype in ("f32", "f16x2", "bf16"):
+    for dtype in ("f32", "f16x2", "f16", "bf16"):
         with HipEvaluator(blob, batch_size=len(planes), plane_words=planes.shape[2], dtype=dtype) as ev:
             p, v = ev.eval(planes)
         row[dtype] = dict(dp=float(np.abs(p - p64).max()), dv=float(np.abs(v - v64).max()),
@@ -43,7 +43,7 @@ dev = torch.device("cuda", 0)
 d_planes = torch.from_numpy(planes.view(np.int64)).to(dev)
 stream = torch.cuda.Stream(device=dev)
 out["timing"] = {}
-for dtype in ("bf16", "f16x2", "f32"):
+for dtype in ("bf16", "f16", "f16x2", "f32"):
     ev = HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype)
     pol = torch.empty((256, d.moves), dtype=torch.float32, device=dev)
     val = torch.empty((256,), dtype=torch.float32, device=dev)

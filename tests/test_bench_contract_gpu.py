@@ -35,6 +35,57 @@ def test_bench_prints_one_json_line_on_stdout():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` with no torchrun in front: the parent (which has not touched the GPU) starts two fresh ranks
+    and relays rank 0's line.  This box has one GPU, so the rehearsal switch puts both ranks on device 0 and runs the
+    collectives over gloo -- the plumbing is what is under test, never the number."""
+    import os
+
+    env = dict(os.environ, BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--settle-seconds", "0", "--selfplay-seconds", "2",
+           "--agreement-plies", "0", "--no-bf16", "--no-f32", "--lanes", "1", "--no-smi"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["per_rank_value"]) == 2 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 256 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
+    assert out["process_group"]["ranks"] == 2
+    for leg in ("selfplay", "selfplay_full_games", "selfplay_config4"):
+        assert out[leg]["ranks"] == 2 and len(out[leg]["node_evals_per_sec_per_rank"]) == 2, leg
+    assert out["selfplay_config4"]["pooled"]["records"] == out["selfplay_config4"]["games"] * 6
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """Under a launcher, WORLD_SIZE != --gpus exits non-zero before anything is measured (no GPU needed to see it)."""
+    import os
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and p.stdout.strip() == ""
+
+
+def test_bench_gpus_n_fails_loudly_where_the_ranks_cannot_run():
+    """`--gpus 2` on a box without a GPU: the parent starts the ranks, they refuse (no CPU path), and the parent exits
+    non-zero with an empty stdout instead of a one-rank line."""
+    import os
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and p.stdout.strip() == "" and "starting 2 ranks" in p.stderr
+
+
+@pytest.mark.gpu
 def test_sustained_mfma_rate_is_a_sane_fraction_of_the_nominal_peak():
     """cattus_hip_mfma_sustained (the `roofline.sustained` figure): between 40 % and 100 % of the nominal peak for every tower
     kind, and the exact-f32 MFMA -- the least power-hungry -- closest to its own."""

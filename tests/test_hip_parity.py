@@ -174,7 +174,10 @@ def test_f16x2_range_large_batchnorm_scales():
     """f16 holds 65504 at most.  Weights are safe whatever their size (each output channel is pre-scaled by a power of two
     and un-scaled exactly in the epilogue); activations are stored as they are.  A stem BatchNorm weight of 200 puts
     the residual stream in the hundreds -- the split tower still tracks the f32 oracle to 22 bits --; one of 1e5 sends
-    it beyond the f16 range, where the epilogue saturates at 65504 instead of producing infinities."""
+    it beyond the f16 range, where the epilogue saturates at 65504 instead of producing infinities -- and COUNTS what it
+    clamped: cattus_stats.saturated is 0 for the first network and > 0 for the second, on every kernel that stores f16
+    activations (register-ring and LDS-ring split conv, the single-term f16 conv), so a caller can tell that the default
+    dtype left its range."""
     from cattus_amd.weights import pack_tensors, seeded_tensors
 
     d = NetDesc(**CHESS, blocks=2, filters=64, vhc=8, phc=8)
@@ -186,7 +189,18 @@ def test_f16x2_range_large_batchnorm_scales():
         blob = pack_tensors(d, t)
         want_p, want_v = oracle.OracleNet(blob).forward(planes)
         with HipEvaluator(blob, batch_size=16, plane_words=1, dtype="f16x2") as ev:
+            assert ev.stats()["saturated"] == 0
             p, v = ev.eval(planes)
+            sat = ev.stats()["saturated"]
+            ev.eval(planes)
+            assert ev.stats()["saturated"] == 2 * sat  # sticky: it accumulates over the evaluator's life
+        assert (sat > 0) == finite_only, (scale, sat)
+        with HipEvaluator(blob, batch_size=16, plane_words=1, dtype="f16") as ev:
+            ev.eval(planes)
+            assert (ev.stats()["saturated"] > 0) == finite_only
+        with HipEvaluator(blob, batch_size=16, plane_words=1, dtype="f32") as ev:
+            ev.eval(planes)
+            assert ev.stats()["saturated"] == 0  # the f32 tower has no range to leave
         assert np.isfinite(p).all() and np.isfinite(v).all()
         if not finite_only:
             assert np.abs(want_p).max() > 20  # the scale did reach the logits
