@@ -11,6 +11,7 @@ The headline dtype is ``f16x2``, the split-precision tower: inside the reference
 and, at search level, the visit distributions of the exact-f32 search.  Beside it the same JSON
 line carries
   bf16                    the same steps on the bf16 tower (throughput mode, 8 significant bits), with its own roofline
+  f16                     the same steps on the single-term f16 tower (throughput mode, 11 significant bits), with its own roofline
   f32                     the same steps on the exact-f32 tower (bit-identical to the CPU oracle), with its own roofline
   search_agreement        what each reduced-cost tower does to the SEARCH: 800-sim searches of the same positions with
                           the f32 tower and with it (cattus_amd/agreement.py)
@@ -43,17 +44,19 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md: the f16 and bf16 forms issue at the same rate
-MFMA_PEAK_TFLOPS = {"f16x2": 2500.0, "bf16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"f16x2": 2500.0, "bf16": 2500.0, "f16": 2500.0, "f32": 157.3}
 # MFMA instructions executed per algorithmic multiply-add term: the split tower computes a_hi w_hi + a_lo w_hi + a_hi w_lo
-MFMA_TERMS = {"f16x2": 3, "bf16": 1, "f32": 1}
+MFMA_TERMS = {"f16x2": 3, "bf16": 1, "f16": 1, "f32": 1}
 DTYPE_NOTE = {
     "f16x2": "split precision: activations and weights as pairs of f16 values (22 significant bits), three f16 MFMA terms per product, "
              "f32 accumulation, f32 heads; inside the reference's cross-runtime tolerance (training/tests/test_net_output.py:28-33)",
     "bf16": "bf16 operands, f32 accumulation: throughput mode, 8 significant bits, outside the reference's tolerance",
+    "f16": "single-term f16 operands (weights pre-scaled per output channel), f32 accumulation, f32 heads: throughput mode, 11 significant "
+           "bits, outside the reference's tolerance; 99.4 % of the f32 search's moves (bf16: 95 %)",
     "f32": "exact-f32 MFMA tower (v_mfma_f32_32x32x2_f32): bit-identical to the CPU oracle",
 }
 # node-evals/s one GPU sustains per dtype (sizes the bounded self-play samples; measured round 3)
-EVAL_CAPACITY = {"f16x2": 135e3, "bf16": 330e3, "f32": 44e3}
+EVAL_CAPACITY = {"f16x2": 135e3, "bf16": 330e3, "f16": 290e3, "f32": 44e3}
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
@@ -433,7 +436,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", choices=["f16x2", "bf16", "f32"], default="f16x2", help="tower of the headline `value` (default: the split-precision tower)")
+    ap.add_argument("--dtype", choices=["f16x2", "bf16", "f16", "f32"], default="f16x2", help="tower of the headline `value` (default: the split-precision tower)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="chess20x256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smi", action="store_true", help="do not sample the device's clock / power under load beside the roofline")
@@ -444,6 +447,7 @@ def main():
     ap.add_argument("--agreement-plies", type=int, default=4, help="searched plies per game of the search agreement leg (0 = skip)")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 (bit-exact) object")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 (throughput mode) object")
+    ap.add_argument("--no-f16", action="store_true", help="skip the f16 (single-term f16 throughput mode) object")
     ap.add_argument("--settle-seconds", type=float, default=0.4,
                     help="untimed steps run for this long IN FRONT of the W warm-up steps (the clock governor needs longer than W steps to settle); 0 = none")
     ap.add_argument("--side-legs-timeout", type=float, default=900.0,
@@ -652,7 +656,8 @@ def main():
             assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
         ev.close()
         return dict(elapsed=elapsed, own_all=own_all, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2,
-                    kernel="tower64_lds_kernel" if launches == 1 else "conv3x3_splitw_kernel" if dtype == "f16x2" else "conv3x3_mfma_v2_kernel",
+                    kernel=("tower64_split_kernel" if dtype == "f16x2" else "tower64_lds_kernel") if launches == 1
+                    else "conv3x3_splitw_kernel" if dtype == "f16x2" else "conv3x3_mfma_v2_kernel",
                     settle_steps=settle_steps, settle_ms=settle_ms, smi=smi, sustained=sustained)
 
     def roofline(dtype, r):
@@ -799,13 +804,13 @@ def main():
             out[name] = {"error": f"{type(exc).__name__}: {exc}"}
             return None
 
-    for dtype, skip, div in (("bf16", args.no_bf16, 1), ("f32", args.no_f32, 10)):
+    for dtype, skip, div in (("bf16", args.no_bf16, 1), ("f16", args.no_f16, 1), ("f32", args.no_f32, 10)):
         if dtype == args.dtype or skip:
             continue
         k = max(5, args.steps // div)
 
         def side(dtype=dtype, k=k, div=div):
-            r = time_evaluator(dtype, k, max(2, args.warmup // div), settle_s=0.2 if dtype == "bf16" else 0.0)
+            r = time_evaluator(dtype, k, max(2, args.warmup // div), settle_s=0.2 if dtype in ("bf16", "f16") else 0.0)
             return side_object(dtype, r) if rank == 0 else None
 
         obj = run_leg(dtype, side)
@@ -825,7 +830,7 @@ def main():
             ta = ag.run_traces("chess", cfg, sp.Net.hip_batched(ev32), opens, 2, args.agreement_plies)
         lines = [op + [c for c, _ in t] for op, t in zip(opens, ta)]
         agreement = {}
-        for dtype in [args.dtype] + ([] if args.no_bf16 or args.dtype == "bf16" else ["bf16"]):
+        for dtype in [args.dtype] + ([] if args.no_bf16 or args.dtype == "bf16" else ["bf16"]) + ([] if args.no_f16 or args.dtype == "f16" else ["f16"]):
             with HipEvaluator(blob, batch_size=games, plane_words=1, dtype=dtype, device=local_rank, flush_us=100) as evx:
                 tb = ag.run_traces("chess", cfg, sp.Net.hip_batched(evx), lines, 2, args.agreement_plies)
             agreement[dtype] = ag.compare_traces(ta, tb)

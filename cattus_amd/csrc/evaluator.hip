@@ -241,6 +241,10 @@ struct cattus_eval {
     // (tower64_lds_kernel; CATTUS_TOWER64=0 selects the per-layer launches, for A/B runs and the equality test)
     bool tower64 = false;
     DevBuf t64_layers;
+    // f16x2 networks with <= 64 filters: the same, in split precision (tower64_split_kernel; weights from the register ring)
+    bool tower64s = false;
+    bool t64s_fuse_heads = true;  // CATTUS_T64S_HEADS=0: the head convs as their own launch on the tower's f32 rows (A/B, the equality test)
+    int t64s_depth = 0;           // CATTUS_T64S_SHAPE=1|2|9: workgroup shape of the resident split tower (kernels.h; 0: by grid size)
     bool pack_separately = false;  // CATTUS_FUSED_STEM=0: plane pack as its own launch in front of the stem (A/B, tests)
     int t64_force_ch = 0;          // CATTUS_T64_CH=2|4: workgroup shape of the resident tower (A/B runs, the row-split test)
     bool split_wfrag = true;       // CATTUS_SPLIT_W=0: f16x2 weights through the LDS ring (conv3x3_split_kernel) instead of the register ring
@@ -546,6 +550,18 @@ int build(cattus_eval* e, const float* p) {
         if ((rc = e->t64_layers.upload(tl.data(), tl.size() * sizeof(Tower64Layer)))) return rc;
     }
 
+    if (e->tuned && e->act == Act::F16S && FP == 64 && e->cpad0 == 32 && e->split_wfrag && 1 + 2 * d.blocks <= (uint32_t)T64S_MAX_LAYERS) {
+        const char* sw = getenv("CATTUS_TOWER64");
+        e->tower64s = !(sw && sw[0] == '0');
+        std::vector<Tower64SplitLayer> tl;
+        tl.push_back(Tower64SplitLayer{e->stem.wf.p, e->stem.b.as<float>(), 0, 1});
+        for (uint32_t i = 0; i < d.blocks; i++) {
+            tl.push_back(Tower64SplitLayer{e->c1[i]->wf.p, e->c1[i]->b.as<float>(), 0, 2});
+            tl.push_back(Tower64SplitLayer{e->c2[i]->wf.p, e->c2[i]->b.as<float>(), 1, 2});
+        }
+        if ((rc = e->t64_layers.upload(tl.data(), tl.size() * sizeof(Tower64SplitLayer)))) return rc;
+    }
+
     // activations
     const size_t bp_ = e->bpad, B = e->cfg.max_batch;
     // bytes per channel of the tower buffers; the f16 towers' last layer writes f32 rows into one of them
@@ -622,6 +638,19 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             int ch = e->slots == 64 && rows / 64 <= 256 ? 4 : 2;
             if (e->t64_force_ch) ch = e->t64_force_ch == 4 && e->slots == 64 ? 4 : 2;  // A/B runs, the row-split test
             launch_tower64(ta, rows, ch, e->t64_layer_steps, st, s0, s1);
+        } else if (e->tower64s) {
+            // the whole split-precision tower in one launch; its output: plain f32 rows in `a` for the f32 head kernels
+            Tower64SplitArgs ta{};
+            ta.planes = d_planes, ta.layers = e->t64_layers.as<Tower64SplitLayer>(), ta.sat = e->conv_opts.saturated;
+            ta.n = n, ta.C = d.planes, ta.w64 = w64, ta.S = S, ta.nlayers = 1 + 2 * d.blocks;
+            if (e->t64s_fuse_heads) {
+                ta.head_w = e->head_w.as<float>(), ta.head_b = e->head_b.as<float>(), ta.hv = L.hv.as<float>();
+                ta.hv_pol = (uint32_t)((e->bpad + 31) / 32 * 32) * e->kvp, ta.kvp = e->kvp, ta.kpp = e->kpp, ta.vhc = d.vhc, ta.ocn = d.vhc + d.phc;
+            } else {
+                ta.out = (float*)a;
+            }
+            hipEvent_t s0 = ev(false), s1 = ev(true);
+            launch_tower64_split(ta, nb * e->slots, e->t64s_depth, st, s0, s1);
         } else {
             // the stem conv expands the planes itself when they fit one 128-byte chunk (every game here); else K0 first
             const bool fused_stem = d.planes <= 32 && e->cpad0 == (uint32_t)act_kc(e->act) && !e->pack_separately;
@@ -670,7 +699,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
         hd.w2 = e->w2.as<float>(), hd.b2 = e->b2.as<float>(), hd.value = d_value;
         hd.slots = e->slots;
         hd.hv_leaves = (e->bpad + 31) / 32 * 32;
-        launch_heads_mfma(head_act(e->act), e->tower64 ? nullptr : a, n, e->fpad, hd, st);
+        launch_heads_mfma(head_act(e->act), e->tower64 || (e->tower64s && e->t64s_fuse_heads) ? nullptr : a, n, e->fpad, hd, st);
     } else {
         TowerView tv;
         tv.x = a, tv.act = Act::F32, tv.sb = F * hw, tv.sk = hw, tv.sp = 1;
@@ -895,6 +924,8 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     const char* t64_ch_env = getenv("CATTUS_T64_CH");
     const char* t64_ls_env = getenv("CATTUS_T64_LS");
     const char* split_w_env = getenv("CATTUS_SPLIT_W");
+    const char* t64s_heads_env = getenv("CATTUS_T64S_HEADS");
+    const char* t64s_d_env = getenv("CATTUS_T64S_SHAPE");
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
     if (!e) return fail(CATTUS_E_NOMEM, "out of memory");
@@ -907,6 +938,9 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->t64_force_ch = t64_ch_env ? atoi(t64_ch_env) : 0;
     e->t64_layer_steps = !(t64_ls_env && atoi(t64_ls_env) == 0);
     e->split_wfrag = !(split_w_env && split_w_env[0] == '0');
+    e->t64s_fuse_heads = !(t64s_heads_env && t64s_heads_env[0] == '0');
+    e->t64s_depth = t64s_d_env ? atoi(t64s_d_env) : 0;
+    if (e->t64s_depth != 1 && e->t64s_depth != 2 && e->t64s_depth != 9) e->t64s_depth = 0;
     e->conv_opts.cb = conv_cb_env ? atoi(conv_cb_env) : 0;
     e->conv_opts.pbw = conv_pbw_env ? atoi(conv_pbw_env) : 0;
     e->hw = d.board * d.board;
@@ -1136,7 +1170,7 @@ CATTUS_API int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, 
     Lane& L = e->lanes[0];
     std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
-    const uint32_t per_fwd = e->tower64 ? 1 : 1 + 2 * e->d.blocks;
+    const uint32_t per_fwd = e->tower64 || e->tower64s ? 1 : 1 + 2 * e->d.blocks;
     TowerTimer tt;
     tt.ev.resize((size_t)2 * per_fwd);
     for (auto& ev : tt.ev) HIP_TRY(hipEventCreate(&ev));

@@ -106,6 +106,34 @@ struct Tower64Args {
 void launch_tower64(const Tower64Args& args, uint32_t rows, int ch, bool layer_steps, hipStream_t st,
                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
+// ---- K1rs resident, split precision: the whole tower of a <= 64-filter f16x2 network in one launch (see kernels.hip) ----
+struct Tower64SplitLayer {
+    const void* wf;     // fragment-ordered (hi, lo) weights (CONV_W_FRAG layout, cout padded to 64)
+    const float* bias;  // [64 biases | 64 inverse scales]
+    int res;            // 1: add the block input (second conv of a residual block)
+    int nch;            // 32-channel chunks of the layer's input: 1 for the stem (planes), 2 otherwise
+};
+struct Tower64SplitArgs {
+    const uint64_t* planes;            // [n][C][w64] bitboards, C <= 32
+    const Tower64SplitLayer* layers;   // device array [nlayers]: stem, then (conv1, conv2) per block
+    float* out;                        // optional: [rows][64] f32, the tower output, rows = boards * tower_slots(S)
+    unsigned* sat;                     // the evaluator's saturation counter (ConvOpts::saturated)
+    uint32_t n, C, w64, S, nlayers;
+    // optional, fused K3: the two 1x1 head convs (+ folded BN + ReLU) in f32 on the resident output, written in the layout the
+    // head FC kernels read (HeadsMfma::hv); head_w [32][64] f32 (value rows first, rows >= ocn zero), head_b [32]
+    const float* head_w;
+    const float* head_b;
+    float* hv;
+    uint32_t hv_pol, kvp, kpp, vhc, ocn;  // hv_pol: element offset of the policy part
+};
+constexpr int T64S_MAX_LAYERS = 81;  // the bias table of all layers lives in LDS (512 B per layer)
+// rows % 256 == 0 (whole boards); one workgroup per board
+// shape (64-slot boards): 1 = one board per workgroup (four one-tile waves), 2 = two boards per workgroup (a wave holds a
+// board's 64 pixels x 32 couts), 9 = shape 1 with a 9-stage weight ring and two stages of pixel look-ahead (A/B); 0 = by grid size
+void launch_tower64_split(const Tower64SplitArgs& args, uint32_t rows, int shape, hipStream_t st, hipEvent_t ev_start = nullptr,
+                          hipEvent_t ev_stop = nullptr);
+hipError_t prepare_tower64_split();  // its dynamic-LDS opt-in; called by prepare_device()
+
 // Generic f32 NCHW direct conv for shapes the MFMA kernel does not cover (any S <= 11, any C).
 // in [b][cin][hw], w [9][cout][cin], out [b][cout][hw]; same summation order as the MFMA f32 kernel.
 void launch_conv3x3_generic(const float* in, const float* w, const float* bias, const float* res, float* out,

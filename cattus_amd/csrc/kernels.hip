@@ -19,6 +19,7 @@
 // so results are bit-identical across batch sizes, batch compositions and to the CPU oracle.  The split-precision and
 // bf16 towers are bit-reproducible and batch-independent too, within the error bounds stated in DESIGN.md section 4.
 #include "kernels.h"
+#include "device_common.h"
 
 #include <hip/hip_ext.h>
 
@@ -29,14 +30,6 @@
 
 namespace cattus {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-
-#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // ------------------------------------------------------------------------------------------
 // K0: plane expansion
@@ -173,44 +166,6 @@ void launch_planes_to_tensor_nchw(const uint64_t* planes, uint32_t n, uint32_t C
 // Tower layout: a board owns 64 pixel slots (board edge <= 8) or 128 (edge 9..11); a workgroup always
 // covers 256 consecutive tower rows = 4 boards of 64 slots or 2 boards of 128.
 
-template <typename T>
-struct Mfma;
-
-template <>
-struct Mfma<__bf16> {
-    typedef bf16x8 frag;
-    static __device__ __forceinline__ void mac(const frag& a, const frag& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-
-// f16 operands (the split-precision tower: DESIGN.md section 3, K1s): same lane map and cycles as the bf16 form
-template <>
-struct Mfma<_Float16> {
-    typedef f16x8 frag;
-    static __device__ __forceinline__ void mac(const frag& a, const frag& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-};
-
-template <>
-struct Mfma<float> {
-    typedef f32x4 frag;
-    // lane half h holds k = 4h + j in element j: the chain visits k = 0,4,1,5,2,6,3,7 of the 8-group
-    static __device__ __forceinline__ void mac(const frag& a, const frag& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
-    }
-};
-
-// Element index of (row, k) of a [rows][K] matrix kept in MFMA fragment order (kernels.h, HeadsMfma).
-template <typename T>
-__host__ __device__ constexpr size_t frag_packed_index(uint32_t row, uint32_t k, uint32_t K) {
-    constexpr uint32_t KSTEP = 32 / sizeof(T), HALF = KSTEP / 2;
-    return ((((size_t)(row >> 5) * (K / KSTEP) + k / KSTEP) * 2 + (k % KSTEP) / HALF) * 32 + (row & 31)) * HALF + k % HALF;
-}
 
 // ---- diagnostic build only (-DCATTUS_STAMPS): per-wave cycle stamps of the v2 tower kernel ------
 #ifdef CATTUS_STAMPS
@@ -232,22 +187,6 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 #define STAMP_FLUSH(wave)
 #endif
 
-// The f16 towers store activations as f16 and clamp them at 65504 instead of letting them overflow to infinity.  A clamped
-// value is a wrong value: it is counted (atomic add on the clamp path only -- a network inside the f16 range never gets
-// here) into the evaluator's sticky counter, which cattus_hip_stats reports as `saturated`.
-__device__ __forceinline__ void note_saturation(const float (&y)[8], bool valid, unsigned* sat) {
-    const float m = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
-    if (valid && m > 65504.0f) {
-        unsigned n = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) n += y[j] > 65504.0f ? 1u : 0u;
-        atomicAdd(sat, n);
-    }
-}
-
-__device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
-    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
-}
 // Workgroup = 8 waves = 256 tower rows x 64 output channels.  Waves 0-3 are MFMA consumers: wave w owns
 // rows w*64 .. w*64+63 (a whole 64-slot board, or half of a 128-slot board) = a 64(cout) x 64(pixel)
 // tile = 2x2 MFMA 32x32 accumulators; waves 4-7 are loaders that do nothing but LDS-DMA.  One barrier per (chunk, kernel row): a step covers the
@@ -264,11 +203,6 @@ constexpr int V2_LDS_ZERO = 3 * V2_SLAB;              // 128 B of zeros
 constexpr int V2_LDS_ACT = V2_LDS_ZERO + 128;         // 2 x 32 KiB
 constexpr int V2_LDS_TOTAL = V2_LDS_ACT + 2 * 32768;  // 139392 B
 
-template <int N>
-__device__ __forceinline__ void wait_vm_barrier() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 
 #ifndef CATTUS_NLOAD
 #define CATTUS_NLOAD 4  // loader waves per workgroup (the kernels assert 4)
@@ -726,7 +660,6 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 //   * a consumer stage is (tap, 16 channels): the hi and lo fragments of 2 weight blocks and 2 pixel blocks (8
 //     ds_read_b128) feed 12 MFMAs, one stage (384 cycles of MFMA issue) of look-ahead.
 // flags & CONV_OUT_F32: the output is written as plain f32 [row][cout] (the last tower layer, for the f32 head kernels).
-constexpr int SP = 144;                                 // LDS row pitch
 constexpr int SP_TAP = 64 * SP;                         // the 64 cout rows of one tap
 constexpr int SP_SLAB = 3 * SP_TAP;                     // 27,648 B = 27 LDS-DMA pieces of 1 KiB
 constexpr int SP_ZERO = 256 * SP;                       // a buffer's zero row (off-board taps read it), behind its 256 rows
@@ -1086,10 +1019,7 @@ __global__ void __launch_bounds__(512, 2)
 // XCD's L2), and while even that grid would leave half of the CUs empty the workgroup covers 128 rows instead of 256
 // (PBW = 1: 32 pixels per consumer wave, half the MFMA chain per wave, twice the workgroups): 14.0 us per launch at 64
 // leaves of chess 20x256, 11.9 at 17 (256-row workgroups: 18.6 / 18.4; the LDS-ring kernel: 22.5 / 22.0).
-constexpr int SW_D = 6;                       // weight stages in flight per consumer wave; divides the 18 stages of a chunk
-constexpr int SW_STAGE = 2048;                // bytes per 32-cout block and stage: hi fragment, lo fragment
 constexpr int sw_lds_total(int cb, int pbw = 2) { return 2 * (128 * pbw * SP + SP) + 128 * pbw * 32 * cb * 4; }  // 139,552 B at CB = 2
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // PBW: 32-pixel blocks per consumer wave.  2: the workgroup covers 256 tower rows (64 pixels per wave); 1 (with CB = 1, for
 // grids that would otherwise leave CUs empty: <= 64 leaves of an 8x8 game at 256 filters): 128 rows, 32 pixels per wave -- twice
@@ -2129,6 +2059,8 @@ hipError_t prepare_device() {
     set(reinterpret_cast<const void*>(&tower64_lds_kernel<4, false, false>), tower64_lds_bytes(4, false));
     set(reinterpret_cast<const void*>(&tower64_lds_kernel<2, true, false>), tower64_lds_bytes(2, false));
     set(reinterpret_cast<const void*>(&tower64_lds_kernel<2, false, false>), tower64_lds_bytes(2, false));
+    const hipError_t e3 = prepare_tower64_split();
+    if (err == hipSuccess) err = e3;
     return err;
 }
 

@@ -9,7 +9,7 @@ TAG=${1:-final}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-QUIET="--lanes 1 --settle-seconds 0 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32 --no-bf16 --no-smi"
+QUIET="--lanes 1 --settle-seconds 0 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32 --no-bf16 --no-f16 --no-smi"
 echo "== bench (defaults)"; timeout -k 10 900 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 tail -c 400 "$OUT/bench.json"; echo
 for dt in f16x2 bf16; do

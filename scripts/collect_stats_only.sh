@@ -6,7 +6,7 @@ TAG=${1:-stats}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-F="--lanes 1 --settle-seconds 0 --no-bf16 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32"
+F="--lanes 1 --settle-seconds 0 --no-bf16 --no-f16 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32"
 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 > "$OUT/bench_evaluator_only.json" 2> "$OUT/bench.err" || exit 1
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py --steps 50 --warmup 5 $F > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || exit 1
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;

@@ -6,7 +6,7 @@ TAG=${1:-heads}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-F="--lanes 1 --settle-seconds 0 --no-bf16 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32"
+F="--lanes 1 --settle-seconds 0 --no-bf16 --no-f16 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32"
 for wl in hex7_6x64 chess20x256; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -o bench -- python3 bench.py --workload $wl --steps 50 --warmup 5 $F > "$OUT/bench_$wl.json" 2> "$OUT/stats_$wl.err" || exit 1
   find "$OUT/stats_$wl" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_$wl.csv" \;

@@ -14,26 +14,30 @@ ROOT = Path(__file__).resolve().parent.parent
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
-def code_object(so: bytes) -> bytes:
+def code_objects(so: bytes):
+    """Every gfx950 code object of the library: one offload bundle per translation unit."""
     i = so.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    n = struct.unpack_from("<Q", so, i + 24)[0]
-    off = i + 32
-    for _ in range(n):
-        o, sz, tl = struct.unpack_from("<QQQ", so, off)
-        off += 24
-        triple = so[off:off + tl].decode()
-        off += tl
-        if "gfx950" in triple:
-            return so[i + o:i + o + sz]
-    raise SystemExit("no gfx950 code object in the library")
+    while i >= 0:
+        n = struct.unpack_from("<Q", so, i + 24)[0]
+        off = i + 32
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", so, off)
+            off += 24
+            triple = so[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple and sz:
+                yield so[i + o:i + o + sz]
+        i = so.find(b"__CLANG_OFFLOAD_BUNDLE__", i + 24)
 
 
 def main():
     lib = ROOT / "cattus_amd" / "libcattus_hip.so"
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(code_object(lib.read_bytes()))
-        f.flush()
-        notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    notes = ""
+    for co in code_objects(lib.read_bytes()):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            notes += subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
     rows = []
     for k in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
         get = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", k).group(1))  # noqa: E731

@@ -15,7 +15,7 @@ ROOT = Path(__file__).resolve().parent.parent
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_on_stdout():
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--settle-seconds", "0", "--selfplay-seconds", "3",
-           "--agreement-plies", "0", "--no-bf16", "--no-f32", "--lanes", "1"]
+           "--agreement-plies", "0", "--no-bf16", "--no-f16", "--no-f32", "--lanes", "1"]
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -45,7 +45,7 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--settle-seconds", "0", "--selfplay-seconds", "2",
-           "--agreement-plies", "0", "--no-bf16", "--no-f32", "--lanes", "1", "--no-smi"]
+           "--agreement-plies", "0", "--no-bf16", "--no-f16", "--no-f32", "--lanes", "1", "--no-smi"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]

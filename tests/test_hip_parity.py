@@ -236,11 +236,13 @@ def test_mfma_tower_equals_generic_checker_on_the_reference_shapes(name, monkeyp
     ("hex11", dict(**hex_game(11), blocks=2, filters=8, vhc=4, phc=4), 2, 37),      # 128-slot boards
     ("hex9", dict(**hex_game(9), blocks=2, filters=40, vhc=16, phc=16), 2, 600),    # 128-slot boards, 600 of them
     ("ttt", dict(planes=3, board=3, moves=9, blocks=5, filters=8, vhc=8, phc=8), 1, 5),
+    ("ttt", dict(planes=3, board=3, moves=9, blocks=0, filters=8, vhc=8, phc=8), 1, 3),  # a stem and nothing else
 ])
-def test_resident_tower_equals_per_layer_launches(game, desc, words, n, monkeypatch):
-    """bf16 networks with <= 64 (padded) filters run their whole tower in one launch with the activations
-    resident in LDS (tower64_lds_kernel, plane pack fused); results are bit-identical to the per-layer
-    launches (CATTUS_TOWER64=0), for whole and ragged batches and after repeated passes."""
+@pytest.mark.parametrize("dtype", ["bf16", "f16x2"])
+def test_resident_tower_equals_per_layer_launches(game, desc, words, n, dtype, monkeypatch):
+    """bf16 and f16x2 networks with <= 64 (padded) filters run their whole tower in one launch with the activations
+    resident in LDS (tower64_lds_kernel / tower64_split_kernel, plane pack fused); results are bit-identical to the
+    per-layer launches (CATTUS_TOWER64=0), for whole and ragged batches and after repeated passes."""
     d = NetDesc(**desc)
     blob = seeded_blob(d, 17)
     rng = np.random.default_rng(5)
@@ -250,10 +252,11 @@ def test_resident_tower_equals_per_layer_launches(game, desc, words, n, monkeypa
     for i in range(hw):
         planes[:, :, i >> 6] |= bits[:, :, i] << np.uint64(i & 63)
     monkeypatch.setenv("CATTUS_TOWER64", "0")
-    with HipEvaluator(blob, batch_size=n, plane_words=words, dtype="bf16") as ev:
+    with HipEvaluator(blob, batch_size=n, plane_words=words, dtype=dtype) as ev:
         want_p, want_v = ev.eval(planes)
+        assert ev.time_tower(min(n, 8), 1)[1] == 1 + 2 * d.blocks  # the per-layer launches
     monkeypatch.delenv("CATTUS_TOWER64")
-    with HipEvaluator(blob, batch_size=n + 3, plane_words=words, dtype="bf16") as ev:
+    with HipEvaluator(blob, batch_size=n + 3, plane_words=words, dtype=dtype) as ev:
         for _ in range(3):
             got_p, got_v = ev.eval(planes)
             assert (got_p == want_p).all() and (got_v == want_v).all()
@@ -261,6 +264,7 @@ def test_resident_tower_equals_per_layer_launches(game, desc, words, n, monkeypa
         sub_p, sub_v = ev.eval(planes[k : 2 * k + 1])
         assert (sub_p == want_p[k : 2 * k + 1]).all() and (sub_v == want_v[k : 2 * k + 1]).all()
         assert ev.time_tower(min(n, 8), 1)[1] == 1  # one tower launch per forward
+        assert ev.stats()["saturated"] == 0
 
 
 def test_resident_tower_row_splits_agree(monkeypatch):

@@ -49,3 +49,19 @@ def test_patch_applies_to_the_reference(tmp_path):
     subprocess.check_call(["patch", "-p1", "-s", "-i", str(patch)], cwd=tmp_path)
     assert "PLANE_WORDS" in (tmp_path / "engine/src/game/mod.rs").read_text()
     assert 'InferenceConfig::Hip { device, dtype }' in (tmp_path / "engine/src/net/mod.rs").read_text()
+
+
+def test_no_compiler_instruction_touches_a_register_with_an_asm_load_in_flight():
+    """The resident split tower keeps its weight ring in registers filled by hand-placed asm loads (hipcc does not count them).
+    The generated gfx950 code is audited for any instruction that reads, copies or overwrites such a register before the
+    `s_waitcnt vmcnt` that covers its load: a `v_mov` at a control-flow merge did exactly that once, and the results were wrong
+    on cold caches only (scripts/audit_inflight_regs.py; kernels.hip takes two minutes and is audited by hand:
+    `python scripts/audit_inflight_regs.py cattus_amd/csrc/kernels.hip`)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "scripts" / "audit_inflight_regs.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "4 kernels with asm statements audited" in p.stderr
