@@ -260,14 +260,14 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
     }
 
 
-TRAFFIC_FILE = "profiles/r03_pmc_hbm_traffic.json"
+TRAFFIC_FILE = "profiles/r04_pmc_hbm_traffic.json"
 
 
 def kernels_sha256() -> str:
-    """Identity of the kernel CODE the traffic counters were collected on: sha256 of kernels.hip with its `//` comments and
-    all white space removed (an edited comment does not make a measurement stale; the file has no block comments and no
-    `//` inside a string literal)."""
-    text = (ROOT / "cattus_amd" / "csrc" / "kernels.hip").read_text()
+    """Identity of the kernel CODE the traffic counters were collected on: sha256 of the kernel sources (device_common.h,
+    kernels.hip, kernels_t64s.hip) with their `//` comments and all white space removed (an edited comment does not make a
+    measurement stale; the files have no block comments and no `//` inside a string literal)."""
+    text = "".join((ROOT / "cattus_amd" / "csrc" / name).read_text() for name in ("device_common.h", "kernels.hip", "kernels_t64s.hip"))
     code = "".join("".join(line.split("//", 1)[0].split()) for line in text.splitlines())
     return hashlib.sha256(code.encode()).hexdigest()
 

@@ -191,6 +191,7 @@ bool is_pinned(const void* p) {
 struct ConvLayer {
     DevBuf w, b;
     DevBuf wf;  // f16x2: the same weights in MFMA fragment order (kernels.h, CONV_W_FRAG)
+    DevBuf wu, bw;  // f16x2, Winograd form: G g G^T as scaled (hi, lo) pairs in fragment order, and its [biases | inverse scales]
     uint32_t cin = 0;  // as laid out on the device (padded for the MFMA path)
 };
 
@@ -243,10 +244,12 @@ struct cattus_eval {
     DevBuf t64_layers;
     // f16x2 networks with <= 64 filters: the same, in split precision (tower64_split_kernel; weights from the register ring)
     bool tower64s = false;
+    DevBuf t64s_bias;
     bool t64s_fuse_heads = true;  // CATTUS_T64S_HEADS=0: the head convs as their own launch on the tower's f32 rows (A/B, the equality test)
     int t64s_depth = 0;           // CATTUS_T64S_SHAPE=1|2|9: workgroup shape of the resident split tower (kernels.h; 0: by grid size)
     bool pack_separately = false;  // CATTUS_FUSED_STEM=0: plane pack as its own launch in front of the stem (A/B, tests)
     int t64_force_ch = 0;          // CATTUS_T64_CH=2|4: workgroup shape of the resident tower (A/B runs, the row-split test)
+    bool winograd = false;         // CATTUS_WINOGRAD=1: 8x8-board layers of the f16x2 tower in Winograd F(2x2, 3x3) form (kernels_wino.hip)
     bool split_wfrag = true;       // CATTUS_SPLIT_W=0: f16x2 weights through the LDS ring (conv3x3_split_kernel) instead of the register ring
     // tile-forcing switches (CATTUS_CONV_CB, CATTUS_CONV_PBW: A/B runs, the tile-equality tests) and the f16 towers' saturation
     // counter: this evaluator's own -- a second evaluator in the process (model1 vs model2) neither re-tiles nor shares them
@@ -347,6 +350,45 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
                 }
         }
         if ((rc = L.b.upload(b.data(), b.size() * sizeof(float)))) return rc;
+        if (e->winograd && &L != &e->stem && wino_supported(e->bpad, cin_pad, cout_pad, e->d.board)) {
+            // Winograd F(2x2, 3x3) form: U = G g G^T per (cout, cin) in float64, one power-of-two scale per output channel over
+            // all 16 frequencies (largest |U 2^s| in [2^10, 2^11)), split into (hi, lo), in the kernel's fragment order
+            static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            std::vector<double> U((size_t)cout * cin * 16);
+            std::vector<float> bwv((size_t)2 * cout_pad, 0.0f);
+            memcpy(bwv.data(), f.b.data(), cout * sizeof(float));
+            std::vector<_Float16> wu((size_t)16 * cout_pad * cin_pad * 2, (_Float16)0.0f);
+            for (uint32_t co = 0; co < cout_pad; co++) {
+                double m = 0.0;
+                if (co < cout)
+                    for (uint32_t ci = 0; ci < cin; ci++) {
+                        double g[3][3], t[4][3];
+                        for (int ky = 0; ky < 3; ky++)
+                            for (int kx = 0; kx < 3; kx++) g[ky][kx] = f.w[((size_t)(ky * 3 + kx) * cout + co) * cin + ci];
+                        for (int i = 0; i < 4; i++)
+                            for (int kx = 0; kx < 3; kx++) t[i][kx] = G[i][0] * g[0][kx] + G[i][1] * g[1][kx] + G[i][2] * g[2][kx];
+                        for (int i = 0; i < 4; i++)
+                            for (int l = 0; l < 4; l++) {
+                                const double u = t[i][0] * G[l][0] + t[i][1] * G[l][1] + t[i][2] * G[l][2];
+                                U[((size_t)co * cin + ci) * 16 + i * 4 + l] = u;
+                                m = std::max(m, fabs(u));
+                            }
+                    }
+                int sh = 0;
+                if (m > 0.0 && std::isfinite(m)) sh = std::min(100, std::max(-100, 10 - ilogb(m)));
+                bwv[cout_pad + co] = ldexpf(1.0f, -sh);
+                if (co >= cout) continue;
+                for (uint32_t ci = 0; ci < cin; ci++)
+                    for (uint32_t fq = 0; fq < 16; fq++) {
+                        const float us = (float)ldexp(U[((size_t)co * cin + ci) * 16 + fq], sh);
+                        const _Float16 hi = (_Float16)us;
+                        wu[wino_frag_index(fq, co, ci, 0, cin_pad)] = hi;
+                        wu[wino_frag_index(fq, co, ci, 1, cin_pad)] = (_Float16)(us - (float)hi);
+                    }
+            }
+            if ((rc = L.bw.upload(bwv.data(), bwv.size() * sizeof(float)))) return rc;
+            if ((rc = L.wu.upload(wu.data(), wu.size() * 2))) return rc;
+        }
         if (e->split_wfrag) {  // the register-ring kernel's layout: a permutation of the rows above
             std::vector<_Float16> wf(w.size());
             for (uint32_t t = 0; t < 9; t++)
@@ -560,6 +602,10 @@ int build(cattus_eval* e, const float* p) {
             tl.push_back(Tower64SplitLayer{e->c2[i]->wf.p, e->c2[i]->b.as<float>(), 1, 2});
         }
         if ((rc = e->t64_layers.upload(tl.data(), tl.size() * sizeof(Tower64SplitLayer)))) return rc;
+        // every layer's [64 biases | 64 inverse scales] in one table (the kernel copies it to LDS with independent loads)
+        if ((rc = e->t64s_bias.alloc(tl.size() * 512))) return rc;
+        for (size_t l = 0; l < tl.size(); l++)
+            HIP_TRY(hipMemcpy((char*)e->t64s_bias.p + l * 512, tl[l].bias, 512, hipMemcpyDeviceToDevice));
     }
 
     // activations
@@ -642,6 +688,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             // the whole split-precision tower in one launch; its output: plain f32 rows in `a` for the f32 head kernels
             Tower64SplitArgs ta{};
             ta.planes = d_planes, ta.layers = e->t64_layers.as<Tower64SplitLayer>(), ta.sat = e->conv_opts.saturated;
+            ta.bias_all = e->t64s_bias.as<float>();
             ta.n = n, ta.C = d.planes, ta.w64 = w64, ta.S = S, ta.nlayers = 1 + 2 * d.blocks;
             if (e->t64s_fuse_heads) {
                 ta.head_w = e->head_w.as<float>(), ta.head_b = e->head_b.as<float>(), ta.hv = L.hv.as<float>();
@@ -664,13 +711,15 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             auto wptr = [&](const ConvLayer& c) { return wfrag ? c.wf.p : c.w.p; };
             launch_conv3x3_mfma(e->act, L.x0.p, wptr(e->stem), e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
                                 fused_stem ? &stem_in : nullptr, wflag | (d.blocks == 0 ? last_flags : 0), e->conv_opts);
+            // a layer in Winograd form where its operands were uploaded (f16x2, 8x8 boards, CATTUS_WINOGRAD=1), else the direct kernel
+            auto conv = [&](const ConvLayer& c, const void* in, const void* res, void* out, int lflags) {
+                hipEvent_t s0 = ev(false), s1 = ev(true);
+                if (c.wu.p) launch_conv3x3_wino(in, c.wu.p, c.bw.as<float>(), res, out, nb, FP, FP, st, s0, s1, lflags, e->conv_opts.saturated);
+                else launch_conv3x3_mfma(e->act, in, wptr(c), c.b.as<float>(), res, out, nb, FP, FP, S, st, s0, s1, nullptr, wflag | lflags, e->conv_opts);
+            };
             for (uint32_t i = 0; i < d.blocks; i++) {
-                s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, a, wptr(*e->c1[i]), e->c1[i]->b.as<float>(), nullptr, t, nb, FP, FP, S, st, s0, s1, nullptr,
-                                    wflag, e->conv_opts);
-                s0 = ev(false), s1 = ev(true);
-                launch_conv3x3_mfma(e->act, t, wptr(*e->c2[i]), e->c2[i]->b.as<float>(), a, y, nb, FP, FP, S, st, s0, s1, nullptr,
-                                    wflag | (i + 1 == d.blocks ? last_flags : 0), e->conv_opts);
+                conv(*e->c1[i], a, nullptr, t, 0);
+                conv(*e->c2[i], t, a, y, i + 1 == d.blocks ? last_flags : 0);
                 std::swap(a, y);
             }
         }
@@ -925,6 +974,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     const char* t64_ls_env = getenv("CATTUS_T64_LS");
     const char* split_w_env = getenv("CATTUS_SPLIT_W");
     const char* t64s_heads_env = getenv("CATTUS_T64S_HEADS");
+    const char* winograd_env = getenv("CATTUS_WINOGRAD");
     const char* t64s_d_env = getenv("CATTUS_T64S_SHAPE");
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
@@ -938,6 +988,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->t64_force_ch = t64_ch_env ? atoi(t64_ch_env) : 0;
     e->t64_layer_steps = !(t64_ls_env && atoi(t64_ls_env) == 0);
     e->split_wfrag = !(split_w_env && split_w_env[0] == '0');
+    e->winograd = winograd_env && winograd_env[0] == '1';
     e->t64s_fuse_heads = !(t64s_heads_env && t64s_heads_env[0] == '0');
     e->t64s_depth = t64s_d_env ? atoi(t64s_d_env) : 0;
     if (e->t64s_depth != 1 && e->t64s_depth != 2 && e->t64s_depth != 9) e->t64s_depth = 0;

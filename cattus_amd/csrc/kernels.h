@@ -77,6 +77,19 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const StemInput* stem = nullptr,
                          int flags = 0, const ConvOpts& opts = ConvOpts());
 
+// ---- K1w: the split-precision conv in Winograd F(2x2, 3x3) form (kernels_wino.hip) ----
+// 8x8 boards only; in / res / out in the F16S layout above; wu = G g G^T as (hi, lo) f16 pairs pre-scaled per output channel, in
+// fragment order [cout / 32][(cin / 16) k-steps x 16 frequencies][hi | lo][lane][8 f16] (wino_frag_index); bias = [cout biases |
+// cout inverse scales] of THAT scaling.  flags: CONV_OUT_F32 as above.
+bool wino_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S);
+inline size_t wino_frag_index(uint32_t f, uint32_t co, uint32_t ci, uint32_t part, uint32_t cin_pad) {
+    const uint32_t nst = cin_pad / 16 * 16, stage = (ci >> 4) * 16 + f, lane = ((ci >> 3) & 1) * 32 + (co & 31);
+    return ((((size_t)(co >> 5) * nst + stage) * 2 + part) * 64 + lane) * 8 + (ci & 7);
+}
+void launch_conv3x3_wino(const void* in, const void* wu, const float* bias, const void* res, void* out, uint32_t bpad, uint32_t cin,
+                         uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, int flags, unsigned* sat);
+hipError_t prepare_wino();  // its dynamic-LDS opt-in; called by prepare_device()
+
 // Diagnostic: one launch of nothing but back-to-back MFMAs of the tower's kind (F16S: f16, BF16, F32: 32x32x2 f32), four
 // waves on each of `cus` workgroups, iters x 4 MFMAs per wave; `out` holds cus * 256 floats.  Returns the launch's FLOPs.
 double launch_mfma_sustain(Act act, int cus, int iters, float* out, hipStream_t st);
@@ -116,6 +129,7 @@ struct Tower64SplitLayer {
 struct Tower64SplitArgs {
     const uint64_t* planes;            // [n][C][w64] bitboards, C <= 32
     const Tower64SplitLayer* layers;   // device array [nlayers]: stem, then (conv1, conv2) per block
+    const float* bias_all;             // [nlayers][64 biases | 64 inverse scales]: every layer's `bias`, contiguous
     float* out;                        // optional: [rows][64] f32, the tower output, rows = boards * tower_slots(S)
     unsigned* sat;                     // the evaluator's saturation counter (ConvOpts::saturated)
     uint32_t n, C, w64, S, nlayers;

@@ -2061,6 +2061,8 @@ hipError_t prepare_device() {
     set(reinterpret_cast<const void*>(&tower64_lds_kernel<2, false, false>), tower64_lds_bytes(2, false));
     const hipError_t e3 = prepare_tower64_split();
     if (err == hipSuccess) err = e3;
+    const hipError_t e4 = prepare_wino();
+    if (err == hipSuccess) err = e4;
     return err;
 }
 

@@ -96,10 +96,7 @@ __global__ void __launch_bounds__(256, 1) tower64_split_kernel(Tower64SplitArgs 
     // ---- bias / inverse-scale table of every layer and the head convs' operands -> LDS.  Ordinary loads, issued behind the
     // ring's first loads: where the compiler waits for one of them it waits for everything older too (loads return in order),
     // and they have all returned before this wave's first counted wait (their values are written to LDS ahead of the barrier) ----
-    for (int i = tid; i < nlayers * 128; i += 256) {
-        const float v = A.layers[i >> 7].bias[i & 127];
-        *reinterpret_cast<float*>(smem + TABLE + i * 4) = v;
-    }
+    for (int i = tid; i < nlayers * 128; i += 256) *reinterpret_cast<float*>(smem + TABLE + i * 4) = A.bias_all[i];  // one table: no pointer chase
     const int HEADW = TABLE + nlayers * 512, HEADB = HEADW + 32 * T64S_HP;  // the fused head convs' operands
     if (A.head_w) {
         for (int i = tid; i < 32 * 64; i += 256) *reinterpret_cast<float*>(smem + HEADW + (i >> 6) * T64S_HP + (i & 63) * 4) = A.head_w[i];
@@ -351,7 +348,10 @@ __global__ void __launch_bounds__(256, 1) tower64_split_kernel(Tower64SplitArgs 
     };
     run_layer(0, std::integral_constant<int, 1>{});
     for (int layer = 1; layer < nlayers; layer++) run_layer(layer, std::integral_constant<int, 2>{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last refills (nobody reads them)
+    // the ring's last refills (nobody reads them).  The ring's registers are operands of the wait: to the compiler they are free from
+    // their last MFMA on, and it would park other values in them while the loads are still on their way
+#pragma unroll
+    for (int d = 0; d < D; d++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[d][0]), "+v"(ring[d][1])::"memory");
 }
 
 void launch_tower64_split(const Tower64SplitArgs& args, uint32_t rows, int shape, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -363,9 +363,9 @@ void launch_tower64_split(const Tower64SplitArgs& args, uint32_t rows, int shape
         CATTUS_LAUNCH_T64S(2, 6, 1, true);
         return;
     }
-    // 64-slot boards: two boards per workgroup from 256 boards up (the grid still covers half of the CUs and every wave runs two
-    // accumulator chains); one board per workgroup below, where the launch is a latency chain and more CUs help
-    if (shape == 0) shape = rows / 64 >= 256 && rows % 128 == 0 ? 2 : 1;
+    // 64-slot boards: one board per workgroup (measured, hex7 6x64: 47 / 53 / 93 us at 128 / 256 / 512 boards against 72 / 77 / 86
+    // with two boards per workgroup, which only pays once every CU holds two of the small workgroups)
+    if (shape == 0) shape = rows / 64 >= 512 && rows % 128 == 0 ? 2 : 1;
     if (rows % 128 != 0) shape = 1;
     if (shape == 2) CATTUS_LAUNCH_T64S(2, 6, 1, false);
     else if (shape == 9) CATTUS_LAUNCH_T64S(1, 9, 2, false);

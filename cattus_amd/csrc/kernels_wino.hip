@@ -1,0 +1,323 @@
+// gfx950 kernels of the Cattus leaf evaluator, part 3: the split-precision 3x3 conv in Winograd F(2x2, 3x3) form (K1w).
+//
+// conv3x3_splitw_kernel issues 36 products per 2x2 output tile and input channel (4 outputs x 9 taps), each as three f16 MFMA
+// terms.  F(2x2, 3x3) needs 16: Y = A^T [ (G g G^T) . (B^T d B) ] A, with the 16 "frequencies" of a tile's 4x4 input patch d as 16
+// independent GEMMs over the input channels -- 2.25x fewer MFMAs for the same layer.  What it costs was measured before this was
+// written (scripts/winograd_gate_a.py -> profiles/r04_winograd_gate_a.json: error against the float64 run 1.06-1.66x the direct
+// form's, inside the reference's cross-runtime tolerance; scripts/probes/winograd_probe.hip -> profiles/r04_winograd_probe.txt:
+// the loop below without its transforms runs 21-23 us per 256 -> 256 layer at batch 256 where the direct loop takes 36 on the
+// same harness).  The price is operand traffic: a wave has to hold all 16 accumulators of its (32 tiles x 32 couts) block until the
+// output transform -- 256 registers -- so there is no room for a second block and every operand fragment feeds one accumulator:
+// 1.33 KiB of fragments per MFMA (the direct kernel: 0.67).  The loop is operand-bound at about half of the MFMA rate, and still
+// 1.6x shorter than the direct loop.
+//
+// Shape: 8x8 boards (64 pixel slots, 16 tiles of 2x2), cin and cout multiples of 64 / 128; the stem and every other shape stay on
+// the direct kernels (same activation layout in HBM, so layers mix freely).
+//   workgroup = 4 waves = 2 boards (32 tiles) x 128 couts; wave w holds the 16 accumulators of (32 tiles, couts 32w .. 32w+31)
+//   U (weights): G g G^T in float64 on the host, scaled per cout by a power of two, split (hi, lo), in MFMA fragment order
+//       [cout / 32][k-step x 16 + f][hi | lo][lane][8 f16]; from L2 straight into a register ring, WN_D stages ahead
+//   d (activations): 32-channel chunks of the 128 pixel rows by LDS-DMA (asm: the compiler neither sees nor counts them), two buffers
+//   V = B^T d B: every thread transforms one (tile, channel pair) per k-step, in f32 on d = hi + lo, splits the 16 values into
+//       (hi, lo) and writes them to the k-step's V image [f][tile][16 ch hi | 16 ch lo]; sliced between the MFMA stages of the
+//       previous k-step, two images
+//   a stage = (k-step of 16 channels, frequency f): 2 ring fragments + 2 ds_read_b128 -> 3 MFMAs into accumulator f
+//   epilogue: Y = A^T M A in registers (per lane: tile r, 16 couts), * 2^-s + bias, + skip, ReLU, clamp, split, stores.
+#include "kernels.h"
+#include "device_common.h"
+
+#include <hip/hip_ext.h>
+
+namespace cattus {
+
+constexpr int WN_D = 8;                    // U stages in flight per wave (16 registers... 8 stages x 2 fragments x 4 VGPRs = 64)
+constexpr int WN_VP = 80;                  // V image row: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad (b128 reads down 16 rows conflict-free)
+constexpr int WN_VF = 32 * WN_VP;          // one frequency: 32 tiles
+constexpr int WN_VIMG = 16 * WN_VF;        // one k-step's V: 40,960 B
+constexpr int WN_DROWS = 128;              // pixel rows of a workgroup: 2 boards x 64 slots
+constexpr int WN_DZERO = WN_DROWS * SP;    // the chunk image's zero row (patch pixels off the board)
+constexpr int WN_DBUF = WN_DZERO + SP;     // 18,576 B
+constexpr int WN_LDS_D = 2 * WN_VIMG;
+constexpr int WN_LDS_TOTAL = WN_LDS_D + 2 * WN_DBUF;  // 119,072 B
+constexpr int WN_P = 5;                    // LDS-DMA pieces per wave and chunk: 4 x 5 = 20 >= the image's 18 KiB pieces
+
+// LDS-DMA of 64 x 16 bytes, hidden from the compiler (it would otherwise order this wave's later LDS reads behind a vmcnt(0) of
+// its own, which also waits for the whole register ring): M0 = the wave-uniform LDS byte address, each lane its own source.
+__device__ __forceinline__ void glds16_asm(const char* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4v;
+
+template <bool HAS_RES>
+__global__ void __launch_bounds__(256, 1)
+    conv3x3_wino_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
+                        const _Float16* __restrict__ res, _Float16* __restrict__ out, unsigned* __restrict__ sat, int cin, int cout,
+                        int flags) {
+    typedef _Float16 T;
+    typedef Mfma<T>::frag frag;
+    constexpr int D = WN_D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nblk = gridDim.x, ncg = cout >> 7;
+    int logical = blockIdx.x;
+    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);  // one XCD: all cout groups of a range of boards
+    const int cout0 = (logical % ncg) * 128 + wave * 32;  // this wave's 32 output channels
+    const int row0 = (logical / ncg) * WN_DROWS;          // first tower row of the workgroup's two boards
+
+    const int nch = cin >> 5;        // 32-channel chunks
+    const int nst = (cin >> 4) * 16; // stages: k-steps x 16 frequencies
+    const uint32_t row_bytes = (uint32_t)cin * 4;
+
+    // ---- the U ring ----
+    const char* wblk = reinterpret_cast<const char*>(wu) + (size_t)(cout0 >> 5) * nst * SW_STAGE;
+    const uint32_t voff0 = lane * 16;
+    u32x4 ring[D][2];
+    auto load_stage = [&](u32x4(&slot)[2], const char* p) {
+        u32x4 l0, l1;
+        asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                     : "=&v"(l0), "=&v"(l1)
+                     : "v"(voff0), "s"(p)
+                     : "memory");
+        slot[0] = l0, slot[1] = l1;
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) load_stage(ring[d], wblk + (size_t)d * SW_STAGE);
+
+    // ---- LDS-DMA of an activation chunk: the padded image of conv3x3_splitw_kernel (row pitch 144, slot 8 re-reads slot 7) ----
+    const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
+    uint32_t off_a[WN_P], dst_a[WN_P];
+#pragma unroll
+    for (int i = 0; i < WN_P; i++) {
+        const int id = min(wave * WN_P + i, 17);
+        const int sidx = id * 64 + lane, irow = sidx / 9, c = min(sidx - irow * 9, 7);
+        off_a[i] = (uint32_t)irow * row_bytes + c * 16;
+        dst_a[i] = id * 1024;
+    }
+    auto issue_chunk = [&](int ch, int buf) {  // chunk ch -> buffer buf
+        const char* src = abase0 + (size_t)ch * 128;
+        const uint32_t dst = WN_LDS_D + buf * WN_DBUF;
+#pragma unroll
+        for (int i = 0; i < WN_P; i++) glds16_asm(src + off_a[i], dst + dst_a[i]);
+    };
+    if (tid < 18) reinterpret_cast<f32x4*>(smem + WN_LDS_D + (tid / 9) * WN_DBUF + WN_DZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue_chunk(0, 0);
+    issue_chunk(1, 1);  // cin >= 64: at least two chunks
+
+    // ---- the transform's item: tile tid & 31 (board t >> 4, tile row (t >> 2) & 3, tile column t & 3), channel pair tid >> 5 ----
+    const int tt = tid & 31, chp = tid >> 5;
+    int drow[16];  // byte offset of each patch pixel's row in a chunk image (+ the channel pair's 4 bytes); the zero row off the board
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int y = 2 * ((tt >> 2) & 3) - 1 + i, x = 2 * (tt & 3) - 1 + j;
+            const bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
+            drow[i * 4 + j] = (ok ? ((tt >> 4) * 64 + y * 8 + x) * SP : WN_DZERO) + chp * 4;
+        }
+    const int vwr = tt * WN_VP + chp * 4;  // where this item's hi pair goes inside a frequency's block (the lo pair 32 further)
+    f32x2 dd[16];                          // the patch as f32, then (in place) B^T d, then B^T d B
+    // kp: which half (16 channels) of the chunk; slices 0..3 read a patch row each, 4..7 do the row transform of a column,
+    // 8..11 the column transform of a row and write its four frequencies.  Everything else: nothing.
+    auto transform_slice = [&](int slice, int dbase, int kp, int vbase) {
+        if (slice < 4) {
+            const int i = slice;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const char* p = smem + dbase + drow[i * 4 + j] + kp * 32;
+                const f16x2v hi = *reinterpret_cast<const f16x2v*>(p), lo = *reinterpret_cast<const f16x2v*>(p + 64);
+                dd[i * 4 + j] = f32x2{(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1]};  // hi + lo is exact in f32
+            }
+        } else if (slice < 8) {
+            const int j = slice - 4;  // column j: B^T over the rows
+            const f32x2 d0 = dd[j], d1 = dd[4 + j], d2 = dd[8 + j], d3 = dd[12 + j];
+            dd[j] = d0 - d2, dd[4 + j] = d1 + d2, dd[8 + j] = d2 - d1, dd[12 + j] = d1 - d3;
+        } else if (slice < 12) {
+            const int i = slice - 8;  // row i: B over the columns, then split and store the frequencies 4 i .. 4 i + 3
+            const f32x2 t0 = dd[i * 4], t1 = dd[i * 4 + 1], t2 = dd[i * 4 + 2], t3 = dd[i * 4 + 3];
+            const f32x2 v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                f32x2 x = v[l];
+                // |V| can reach 4 x 65504: saturate rather than overflow (activations that large are counted as saturated already)
+                x = __builtin_elementwise_min(__builtin_elementwise_max(x, f32x2{-65504.0f, -65504.0f}), f32x2{65504.0f, 65504.0f});
+                f16x2v hi, lo;
+                hi[0] = (T)x[0], hi[1] = (T)x[1];
+                lo[0] = (T)(x[0] - (float)hi[0]), lo[1] = (T)(x[1] - (float)hi[1]);
+                char* q = smem + vbase + (i * 4 + l) * WN_VF + vwr;
+                *reinterpret_cast<f16x2v*>(q) = hi;
+                *reinterpret_cast<f16x2v*>(q + 32) = lo;
+            }
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; f++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[f][e] = 0.0f;
+
+    // ---- prologue: both chunks and the ring's first stages have landed; V of k-step 0 ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 12; s++) transform_slice(s, WN_LDS_D, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int vrd = r * WN_VP + h * 16;  // this lane's fragment inside a frequency's block: tile r, channels 8 h .. 8 h + 7 (lo 32 further)
+    // One k-step: 16 stages on the V image at `vimg`, with the transform of the NEXT k-step (chunk image at `dbase`, half kp, into
+    // the other V image) sliced in between.  JB: the stage's index inside the chunk body (0 or 16), which fixes the wait counts.
+    auto kstep = [&](int s0, int vimg, int dbase, int kp, int vnext, auto jb_tag) {
+        constexpr int JB = decltype(jb_tag)::value;
+        frag vh[2], vl[2];
+        vh[0] = *reinterpret_cast<const frag*>(smem + vimg + vrd);
+        vl[0] = *reinterpret_cast<const frag*>(smem + vimg + vrd + 32);
+#pragma unroll
+        for (int f = 0; f < 16; f++) {
+            const int cur = f & 1, nxt = cur ^ 1;
+            if (f + 1 < 16) {  // one stage of look-ahead on the V fragments (never across the k-step: the next image is being written)
+                vh[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + 1) * WN_VF + vrd);
+                vl[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + 1) * WN_VF + vrd + 32);
+            }
+            // all but the youngest 2 (D - 1) ring loads have returned -- plus, for the D stages whose own loads went out before this
+            // body's LDS-DMA (issued between its stages 15 and 16), those WN_P younger DMA instructions
+            {
+                const int j = JB + f;  // a constant once the loop is unrolled: the branch below folds
+                u32x4 r0 = ring[f % D][0], r1 = ring[f % D][1];
+                if (j >= 16 && j < 16 + D) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(2 * (D - 1) + WN_P));
+                else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(2 * (D - 1)));
+                ring[f % D][0] = r0, ring[f % D][1] = r1;
+            }
+            const frag uh = __builtin_bit_cast(frag, ring[f % D][0]);
+            const frag ul = __builtin_bit_cast(frag, ring[f % D][1]);
+            Mfma<T>::mac(ul, vh[cur], acc[f]);
+            Mfma<T>::mac(uh, vl[cur], acc[f]);
+            Mfma<T>::mac(uh, vh[cur], acc[f]);
+            {  // refill D stages ahead; past the layer's end the last stage is re-read (the count of loads in flight stays fixed)
+                const int sn = min(s0 + f + D, nst - 1);
+                load_stage(ring[f % D], wblk + (size_t)sn * SW_STAGE);
+            }
+            transform_slice(f, dbase, kp, vnext);
+        }
+    };
+    for (int c = 0; c < nch; c++) {
+        const int dcur = WN_LDS_D + (c & 1) * WN_DBUF, dnext = WN_LDS_D + ((c + 1) & 1) * WN_DBUF;
+        // k-step 2c on image 0; meanwhile V of k-step 2c + 1 (the chunk's second half) -> image 1
+        kstep(c * 32, 0, dcur, 1, WN_VIMG, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // image 1 is complete, image 0 and chunk c are free
+        issue_chunk(min(c + 2, nch - 1), c & 1);                           // -> the buffer chunk c was in (past the end: a re-read nobody uses)
+        // k-step 2c + 1 on image 1; meanwhile V of k-step 2c + 2 (the next chunk's first half) -> image 0
+        kstep(c * 32 + 16, WN_VIMG, dnext, 0, 0, std::integral_constant<int, 16>{});
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // the ring's last refills (nobody reads them) and the last DMA.  The ring's registers are operands of the wait: to the compiler
+    // they are free from their last MFMA on, and it would park epilogue values in them while the loads are still on their way
+    static_assert(D == 8, "the drain below names every ring slot");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[1][0]), "+v"(ring[1][1]), "+v"(ring[2][0]), "+v"(ring[2][1]), "+v"(ring[3][0]),
+                   "+v"(ring[3][1]), "+v"(ring[4][0]), "+v"(ring[4][1]), "+v"(ring[5][0]), "+v"(ring[5][1]), "+v"(ring[6][0]), "+v"(ring[6][1]),
+                   "+v"(ring[7][0]), "+v"(ring[7][1])
+                 :
+                 : "memory");
+
+    // ---- output transform: per lane and accumulator element, Y = A^T M A over the 16 frequencies (f = 4 i + l) ----
+    // A^T = [1 1 1 0; 0 1 -1 -1]: Z[i][0] = M[i][0] + M[i][1] + M[i][2], Z[i][1] = M[i][1] - M[i][2] - M[i][3], then the same over i.
+    f32x16 y[4];  // y[2 p + q]: output pixel (2 ty + p, 2 tx + q) of the lane's tile
+#pragma unroll
+    for (int q = 0; q < 2; q++) {  // one output column at a time: 64 registers of Z instead of 128
+        f32x16 z[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) z[i] = q == 0 ? acc[i * 4] + acc[i * 4 + 1] + acc[i * 4 + 2] : acc[i * 4 + 1] - acc[i * 4 + 2] - acc[i * 4 + 3];
+        y[q] = z[0] + z[1] + z[2];
+        y[2 + q] = z[1] - z[2] - z[3];
+    }
+    // ---- epilogue: lane (tile r, half h) holds couts cout0 + 8 g + 4 h + i (g, i < 4) of the tile's four pixels ----
+    const int board = r >> 4, ty = (r >> 2) & 3, tx = r & 3;
+    const size_t orow = (size_t)cout * 2;  // f16 elements per row of `res` / `out`
+    const int ocol = (cout0 >> 5) * 64 + h * 4;  // hi of couts cout0 + 4 h ..; the lo values 32 elements further; + 8 g per group
+    f32x4 bv[4], dv[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        bv[g] = *reinterpret_cast<const f32x4*>(bias + cout0 + g * 8 + h * 4);
+        dv[g] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + g * 8 + h * 4);
+    }
+#pragma unroll
+    for (int pq = 0; pq < 4; pq++) {
+        const size_t row = (size_t)row0 + board * 64 + (2 * ty + (pq >> 1)) * 8 + 2 * tx + (pq & 1);
+        f16x4v sh[4], sl[4];
+        if (HAS_RES) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                sh[g] = *reinterpret_cast<const f16x4v*>(res + row * orow + ocol + g * 8);
+                sl[g] = *reinterpret_cast<const f16x4v*>(res + row * orow + ocol + g * 8 + 32);
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int g = half * 2 + q;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float x = __builtin_fmaf(y[pq][g * 4 + i], dv[g][i], bv[g][i]);  // the inverse weight scale is a power of two: exact
+                    if (HAS_RES) x = x + ((float)sh[g][i] + (float)sl[g][i]);
+                    v[q * 4 + i] = x > 0.0f ? x : 0.0f;
+                }
+            }
+            if (flags & CONV_OUT_F32) {  // the tower's last layer: plain f32 rows for the head kernels
+                float* of = reinterpret_cast<float*>(out) + row * (size_t)cout + cout0 + h * 4;
+#pragma unroll
+                for (int q = 0; q < 2; q++) *reinterpret_cast<f32x4*>(of + (half * 2 + q) * 8) = f32x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+            } else {
+                note_saturation(v, true, sat);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int g = half * 2 + q;
+                    f16x4v hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float yc = v[q * 4 + i] < 65504.0f ? v[q * 4 + i] : 65504.0f;
+                        hi[i] = (T)yc;
+                        lo[i] = (T)(yc - (float)hi[i]);
+                    }
+                    *reinterpret_cast<f16x4v*>(out + row * orow + ocol + g * 8) = hi;
+                    *reinterpret_cast<f16x4v*>(out + row * orow + ocol + g * 8 + 32) = lo;
+                }
+            }
+        }
+    }
+}
+
+bool wino_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S) {
+    return S == 8 && cin >= 64 && cin % 32 == 0 && cout % 128 == 0 && bpad % 2 == 0;
+}
+
+void launch_conv3x3_wino(const void* in, const void* wu, const float* bias, const void* res, void* out, uint32_t bpad, uint32_t cin,
+                         uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, int flags, unsigned* sat) {
+    typedef _Float16 H;
+    const dim3 grid((bpad / 2) * (cout / 128));
+    if (res)
+        hipExtLaunchKernelGGL((conv3x3_wino_kernel<true>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, (const H*)in, (const H*)wu,
+                              bias, (const H*)res, (H*)out, sat, (int)cin, (int)cout, flags);
+    else
+        hipExtLaunchKernelGGL((conv3x3_wino_kernel<false>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, (const H*)in, (const H*)wu,
+                              bias, (const H*)res, (H*)out, sat, (int)cin, (int)cout, flags);
+}
+
+hipError_t prepare_wino() {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_TOTAL);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_TOTAL);
+    return err != hipSuccess ? err : e2;
+}
+
+}  // namespace cattus

@@ -21,6 +21,8 @@ pub enum HipDtype {
     Bf16 = 1,
     /// split precision (pairs of f16 values): inside the cross-runtime tolerance of `training/tests/test_net_output.py`
     F16x2 = 2,
+    /// single-term f16 operands, f32 accumulation (throughput mode, 11 significant bits)
+    F16 = 3,
 }
 
 #[repr(C)]
@@ -43,6 +45,8 @@ pub struct CattusStats {
     /// == metric `model.run_duration` (EMA 0.99, util/metric.rs:16-19)
     pub run_seconds_ema: f64,
     pub run_seconds_total: f64,
+    /// f16x2 / f16 towers: activation values clamped at the f16 range since creation; > 0 means this network needs dtype f32
+    pub saturated: u64,
 }
 
 #[repr(C)]

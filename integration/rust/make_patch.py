@@ -168,7 +168,7 @@ def config_py(t: str) -> str:
 class HipConfig:
     engine: Literal["hip"] = "hip"
     device: int = 0
-    dtype: Literal["f16x2", "bf16", "f32"] = "f16x2"
+    dtype: Literal["f16x2", "bf16", "f16", "f32"] = "f16x2"
 
 
 InferenceConfig = ExecutorchConfig | TorchPyConfig | OnnxTractConfig | OnnxOrtConfig | HipConfig

@@ -40,6 +40,9 @@ def audit_kernel(name: str, lines: list) -> list:
             continue
         if not t or t.startswith(";") or t.startswith("."):
             continue
+        if in_asm and t.startswith("global_load_lds"):
+            inflight.append(set())  # LDS-DMA: counted by vmcnt like a load, but it writes no register
+            continue
         if in_asm and t.startswith("global_load_"):
             inflight.append(regs(t.split()[1].rstrip(",")))
             continue

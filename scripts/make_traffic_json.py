@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/rNN_pmc_hbm_traffic.json from the per-dtype PMC summaries of scripts/collect_profiles.sh:
-    python scripts/make_traffic_json.py gpurun_out/TAG > profiles/r03_pmc_hbm_traffic.json
+    python scripts/make_traffic_json.py gpurun_out/TAG > profiles/r04_pmc_hbm_traffic.json
 The file carries the sha256 of the code of cattus_amd/csrc/kernels.hip (comments and white space removed) the passes ran on; bench.py withholds the traffic figure
 when the kernels have changed since (it cannot collect PMC counters inside its own process)."""
 import hashlib
@@ -17,9 +17,9 @@ tag = Path(sys.argv[1])
 # 16384 x 256 activations in and out (+ the skip rows in 20 of them) at the dtype's bytes per channel, the layer's weights once
 ACT = 16384 * 256
 ALG = {}
-for dtype, abytes, wbytes in (("bf16", 2, 2), ("f16x2", 4, 4), ("f32", 4, 4)):
+for dtype, abytes, wbytes in (("bf16", 2, 2), ("f16", 2, 2), ("f16x2", 4, 4), ("f32", 4, 4)):
     w = 9 * 256 * 256 * wbytes
-    stem = 256 * 144 + 9 * 256 * (64 if dtype == "bf16" else 32) * wbytes + ACT * abytes
+    stem = 256 * 144 + 9 * 256 * (64 if abytes == 2 else 32) * wbytes + ACT * abytes
     ALG[dtype] = (stem + 20 * (2 * ACT * abytes + w) + 20 * (3 * ACT * abytes + w)) / 41
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/collect_profiles.sh) -- python3 bench.py --dtype D --steps 5 "
@@ -41,8 +41,8 @@ def base_name(k: str) -> str:
     return k.replace("void ", "").replace("cattus::", "").split("<")[0].split("(")[0].strip()
 
 
-TOWER = {"f16x2": "conv3x3_splitw_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
-for dtype in ("f16x2", "bf16", "f32"):
+TOWER = {"f16x2": "conv3x3_splitw_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
+for dtype in ("f16x2", "bf16", "f16", "f32"):
     f = tag / f"pmc_summary_{dtype}.json"
     if not f.exists():
         continue
