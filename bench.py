@@ -47,6 +47,13 @@ sys.path.insert(0, str(ROOT))
 MFMA_PEAK_TFLOPS = {"f16x2": 2500.0, "bf16": 2500.0, "f16": 2500.0, "f32": 157.3}
 # MFMA instructions executed per algorithmic multiply-add term: the split tower computes a_hi w_hi + a_lo w_hi + a_hi w_lo
 MFMA_TERMS = {"f16x2": 3, "bf16": 1, "f16": 1, "f32": 1}
+
+
+def mfma_terms(dtype: str, kernel: str) -> float:
+    """MFMA instructions per algorithmic multiply-add of the tower kernel: the Winograd F(2x2, 3x3) form of the split tower needs
+    16 instead of 36 products per 2x2 output tile and input channel, each still three f16 terms."""
+    return MFMA_TERMS[dtype] * (16.0 / 36.0 if kernel == "conv3x3_wino_kernel" else 1.0)
+
 DTYPE_NOTE = {
     "f16x2": "split precision: activations and weights as pairs of f16 values (22 significant bits), three f16 MFMA terms per product, "
              "f32 accumulation, f32 heads; inside the reference's cross-runtime tolerance (training/tests/test_net_output.py:28-33)",
@@ -311,8 +318,11 @@ def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, ma
     # search threads: the CPU share of this rank minus room for the two evaluation threads, the HIP runtime's
     # threads and the main thread (15 search threads on a 16-CPU share starved them: 261 k vs 337 k node-evals/s)
     threads = search_threads(sp, world)
-    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype=dtype, device=local_rank) as ev:
-        cfg = sp.make_config(sim_num=sims, batch_size=256, threads=threads, concurrent_games=slots, cache_size=1000000,
+    # model.batch_size as a user would configure it: 256, or the number of concurrent games where that is smaller (one leaf per tree
+    # in flight: a batch can never hold more; the evaluator then also picks the kernels made for small batches)
+    bsz = min(256, slots)
+    with HipEvaluator(blob, batch_size=bsz, plane_words=1, dtype=dtype, device=local_rank) as ev:
+        cfg = sp.make_config(sim_num=sims, batch_size=bsz, threads=threads, concurrent_games=slots, cache_size=1000000,
                              first_game=rank, game_stride=world, seed=1, max_game_plies=max_game_plies,
                              **SELFPLAY_SETTINGS)  # random streams are per global game index
         if world > 1:  # all ranks start the leg together: its rate is the sum of the ranks' evaluations over the slowest rank's time
@@ -654,10 +664,9 @@ def main():
             sync_all()
             elapsed2 = max_over_ranks(time.perf_counter() - t0)
             assert bool((d_policy2 == d_policy).all()) and bool((d_value2 == d_value).all())  # lanes agree bit for bit
+        kernel = ev.tower_kernel()
         ev.close()
-        return dict(elapsed=elapsed, own_all=own_all, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2,
-                    kernel=("tower64_split_kernel" if dtype == "f16x2" else "tower64_lds_kernel") if launches == 1
-                    else "conv3x3_splitw_kernel" if dtype == "f16x2" else "conv3x3_mfma_v2_kernel",
+        return dict(elapsed=elapsed, own_all=own_all, steps=steps, launch_us=launch_us, launches=launches, elapsed2=elapsed2, kernel=kernel,
                     settle_steps=settle_steps, settle_ms=settle_ms, smi=smi, sustained=sustained)
 
     def roofline(dtype, r):
@@ -676,14 +685,14 @@ def main():
             # kernel it says what share of the ELAPSED matrix-pipe cycles the kernel fills
             scale = smi["sclk_mhz"] / 2400.0
             under_load = dict(smi, source="amdgpu sysfs (pp_dpm_sclk, hwmon power1_average) of this device while the same steps run (untimed); what rocm-smi prints",
-                              peak_at_this_clock=peak * scale, mfma_pipe_frac_at_this_clock=MFMA_TERMS[dtype] * achieved / (peak * scale))
+                              peak_at_this_clock=peak * scale, mfma_pipe_frac_at_this_clock=mfma_terms(dtype, r["kernel"]) * achieved / (peak * scale))
         sustained = None
         if r.get("sustained"):
             # the nominal peak is a 2.4 GHz figure; under MFMA load the part's power management sets the clock.  A kernel of
             # nothing but back-to-back MFMAs of this kind (one wave per SIMD, operands in registers, ~50 us launches for 1 s)
             # is what the pipe can deliver on THIS device, measured in this run right behind the timed steps
             sustained = dict(tflops=r["sustained"], frac_of_nominal=r["sustained"] / peak,
-                             mfma_pipe_frac_of_sustained=MFMA_TERMS[dtype] * achieved / r["sustained"],
+                             mfma_pipe_frac_of_sustained=mfma_terms(dtype, r["kernel"]) * achieved / r["sustained"],
                              how="cattus_hip_mfma_sustained: back-to-back MFMAs of the tower's kind on every SIMD, no memory traffic, 1 s")
         return {
             "kernel": r["kernel"],
@@ -700,8 +709,8 @@ def main():
                                "can exceed ms_per_step by 1-2 % -- `achieved` and `frac` are low by that much, never high",
             "launches_per_step": r["launches"],
             "flop_per_launch": flop_per_launch,
-            "mfma_terms_per_multiply_add": MFMA_TERMS[dtype],
-            "mfma_pipe_frac": MFMA_TERMS[dtype] * achieved / peak,
+            "mfma_terms_per_multiply_add": mfma_terms(dtype, r["kernel"]),
+            "mfma_pipe_frac": mfma_terms(dtype, r["kernel"]) * achieved / peak,
             "peak_of": "f16 / bf16 32x32x16 MFMA, dense, at the 2.4 GHz peak clock" if dtype != "f32" else "f32 32x32x2 MFMA, at the 2.4 GHz peak clock",
             "under_load": under_load,
             "sustained": sustained,

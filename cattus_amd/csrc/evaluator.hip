@@ -249,7 +249,11 @@ struct cattus_eval {
     int t64s_depth = 0;           // CATTUS_T64S_SHAPE=1|2|9: workgroup shape of the resident split tower (kernels.h; 0: by grid size)
     bool pack_separately = false;  // CATTUS_FUSED_STEM=0: plane pack as its own launch in front of the stem (A/B, tests)
     int t64_force_ch = 0;          // CATTUS_T64_CH=2|4: workgroup shape of the resident tower (A/B runs, the row-split test)
-    bool winograd = false;         // CATTUS_WINOGRAD=1: 8x8-board layers of the f16x2 tower in Winograd F(2x2, 3x3) form (kernels_wino.hip)
+    // f16x2, 8x8 boards, filters a multiple of 128: every layer behind the stem in Winograd F(2x2, 3x3) form (kernels_wino.hip).
+    // Chosen once, when the evaluator is created -- never per batch, so that a leaf's result does not depend on the batch it came
+    // in: for max_batch >= 192 (below that the direct kernels' small tiles win: 14 against 33 us per launch at 64 leaves of chess
+    // 20x256, 42.8 against 37.5 at 256); CATTUS_WINOGRAD=0 / 1 forbids / forces it.
+    bool winograd = false;
     bool split_wfrag = true;       // CATTUS_SPLIT_W=0: f16x2 weights through the LDS ring (conv3x3_split_kernel) instead of the register ring
     // tile-forcing switches (CATTUS_CONV_CB, CATTUS_CONV_PBW: A/B runs, the tile-equality tests) and the f16 towers' saturation
     // counter: this evaluator's own -- a second evaluator in the process (model1 vs model2) neither re-tiles nor shares them
@@ -710,11 +714,13 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             const int wflag = wfrag ? CONV_W_FRAG : 0;
             auto wptr = [&](const ConvLayer& c) { return wfrag ? c.wf.p : c.w.p; };
             launch_conv3x3_mfma(e->act, L.x0.p, wptr(e->stem), e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
-                                fused_stem ? &stem_in : nullptr, wflag | (d.blocks == 0 ? last_flags : 0), e->conv_opts);
-            // a layer in Winograd form where its operands were uploaded (f16x2, 8x8 boards, CATTUS_WINOGRAD=1), else the direct kernel
+                                fused_stem ? &stem_in : nullptr,
+                                wflag | (d.blocks == 0 || (e->act == Act::F16S && e->c1[0]->wu.p) ? last_flags : 0), e->conv_opts);
+            // f16x2 with CATTUS_WINOGRAD=1 on 8x8 boards: every layer behind the stem in Winograd form, f32 rows between the layers
+            const bool wino = d.blocks > 0 && e->c1[0]->wu.p != nullptr;
             auto conv = [&](const ConvLayer& c, const void* in, const void* res, void* out, int lflags) {
                 hipEvent_t s0 = ev(false), s1 = ev(true);
-                if (c.wu.p) launch_conv3x3_wino(in, c.wu.p, c.bw.as<float>(), res, out, nb, FP, FP, st, s0, s1, lflags, e->conv_opts.saturated);
+                if (wino) launch_conv3x3_wino((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
                 else launch_conv3x3_mfma(e->act, in, wptr(c), c.b.as<float>(), res, out, nb, FP, FP, S, st, s0, s1, nullptr, wflag | lflags, e->conv_opts);
             };
             for (uint32_t i = 0; i < d.blocks; i++) {
@@ -916,6 +922,16 @@ CATTUS_API const char* cattus_hip_last_error(void) { return g_last_error.c_str()
 CATTUS_API const char* cattus_hip_version(void) { return "cattus_hip 0.2 (gfx950)"; }
 CATTUS_API const char* cattus_hip_runtime_note(void) { return g_runtime_note.c_str(); }
 
+CATTUS_API const char* cattus_hip_tower_kernel(const cattus_eval* e) {
+    if (!e) return "";
+    if (e->simple) return "policy_fc_kernel";
+    if (!e->tuned) return "conv3x3_generic_kernel";
+    if (e->tower64) return "tower64_lds_kernel";
+    if (e->tower64s) return "tower64_split_kernel";
+    if (e->act == Act::F16S) return e->d.blocks > 0 && e->c1[0]->wu.p ? "conv3x3_wino_kernel" : e->split_wfrag ? "conv3x3_splitw_kernel" : "conv3x3_split_kernel";
+    return "conv3x3_mfma_v2_kernel";
+}
+
 CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattus_eval_config* cfg, cattus_eval** out) {
     if (!out) return fail(CATTUS_E_INVALID, "out is NULL");
     *out = nullptr;
@@ -988,7 +1004,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->t64_force_ch = t64_ch_env ? atoi(t64_ch_env) : 0;
     e->t64_layer_steps = !(t64_ls_env && atoi(t64_ls_env) == 0);
     e->split_wfrag = !(split_w_env && split_w_env[0] == '0');
-    e->winograd = winograd_env && winograd_env[0] == '1';
+    e->winograd = winograd_env ? winograd_env[0] == '1' : cfg->max_batch >= 192;
     e->t64s_fuse_heads = !(t64s_heads_env && t64s_heads_env[0] == '0');
     e->t64s_depth = t64s_d_env ? atoi(t64s_d_env) : 0;
     if (e->t64s_depth != 1 && e->t64s_depth != 2 && e->t64s_depth != 9) e->t64s_depth = 0;

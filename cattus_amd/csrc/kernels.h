@@ -78,16 +78,17 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
                          int flags = 0, const ConvOpts& opts = ConvOpts());
 
 // ---- K1w: the split-precision conv in Winograd F(2x2, 3x3) form (kernels_wino.hip) ----
-// 8x8 boards only; in / res / out in the F16S layout above; wu = G g G^T as (hi, lo) f16 pairs pre-scaled per output channel, in
-// fragment order [cout / 32][(cin / 16) k-steps x 16 frequencies][hi | lo][lane][8 f16] (wino_frag_index); bias = [cout biases |
-// cout inverse scales] of THAT scaling.  flags: CONV_OUT_F32 as above.
+// 8x8 boards only; in / res / out are PLAIN F32 rows [row][channel] (what CONV_OUT_F32 writes: a tower in this form keeps f32
+// activations between its layers); wu = G g G^T as (hi, lo) f16 pairs pre-scaled per output channel, in fragment order
+// [cout / 32][(cin / 16) k-steps x 16 frequencies][hi | lo][lane][8 f16] (wino_frag_index); bias = [cout biases | cout inverse
+// scales] of THAT scaling; sat: counts threads whose transformed inputs left the f16 range.
 bool wino_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S);
 inline size_t wino_frag_index(uint32_t f, uint32_t co, uint32_t ci, uint32_t part, uint32_t cin_pad) {
     const uint32_t nst = cin_pad / 16 * 16, stage = (ci >> 4) * 16 + f, lane = ((ci >> 3) & 1) * 32 + (co & 31);
     return ((((size_t)(co >> 5) * nst + stage) * 2 + part) * 64 + lane) * 8 + (ci & 7);
 }
-void launch_conv3x3_wino(const void* in, const void* wu, const float* bias, const void* res, void* out, uint32_t bpad, uint32_t cin,
-                         uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, int flags, unsigned* sat);
+void launch_conv3x3_wino(const float* in, const void* wu, const float* bias, const float* res, float* out, uint32_t bpad, uint32_t cin,
+                         uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat);
 hipError_t prepare_wino();  // its dynamic-LDS opt-in; called by prepare_device()
 
 // Diagnostic: one launch of nothing but back-to-back MFMAs of the tower's kind (F16S: f16, BF16, F32: 32x32x2 f32), four

@@ -11,8 +11,11 @@
 // 1.33 KiB of fragments per MFMA (the direct kernel: 0.67).  The loop is operand-bound at about half of the MFMA rate, and still
 // 1.6x shorter than the direct loop.
 //
-// Shape: 8x8 boards (64 pixel slots, 16 tiles of 2x2), cin and cout multiples of 64 / 128; the stem and every other shape stay on
-// the direct kernels (same activation layout in HBM, so layers mix freely).
+// Shape: 8x8 boards (64 pixel slots, 16 tiles of 2x2), cin and cout multiples of 64 / 128.  A tower runs in this form as a whole
+// (every layer but the stem): between its layers the activations are PLAIN F32 rows [row][channel] -- what the split tower's last
+// layer writes for the heads anyway (CONV_OUT_F32), so the stem is the direct kernel with that flag and the heads do not change.
+// The input transform then reads f32 (no hi + lo reassembly: 5 of its 21 instructions per value) and the epilogue writes f32 (no
+// split, no clamp); only the transformed operands U and V are (hi, lo) pairs.
 //   workgroup = 4 waves = 2 boards (32 tiles) x 128 couts; wave w holds the 16 accumulators of (32 tiles, couts 32w .. 32w+31)
 //   U (weights): G g G^T in float64 on the host, scaled per cout by a power of two, split (hi, lo), in MFMA fragment order
 //       [cout / 32][k-step x 16 + f][hi | lo][lane][8 f16]; from L2 straight into a register ring, WN_D stages ahead
@@ -27,6 +30,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 namespace cattus {
 
 constexpr int WN_D = 8;                    // U stages in flight per wave (16 registers... 8 stages x 2 fragments x 4 VGPRs = 64)
@@ -34,10 +39,11 @@ constexpr int WN_VP = 80;                  // V image row: 16 ch hi (32 B) | 16 
 constexpr int WN_VF = 32 * WN_VP;          // one frequency: 32 tiles
 constexpr int WN_VIMG = 16 * WN_VF;        // one k-step's V: 40,960 B
 constexpr int WN_DROWS = 128;              // pixel rows of a workgroup: 2 boards x 64 slots
-constexpr int WN_DZERO = WN_DROWS * SP;    // the chunk image's zero row (patch pixels off the board)
-constexpr int WN_DBUF = WN_DZERO + SP;     // 18,576 B
+constexpr int WN_DZERO = WN_DROWS * SP;    // behind the rows: a zero AREA of 28 rows -- a patch pixel off the board is read at
+constexpr int WN_DBUF = WN_DZERO + 28 * SP;  // zero area + the pixel's offset inside the patch ((3 * 8 + 3) rows at most): 22,464 B
 constexpr int WN_LDS_D = 2 * WN_VIMG;
-constexpr int WN_LDS_TOTAL = WN_LDS_D + 2 * WN_DBUF;  // 119,072 B
+constexpr int WN_LDS_TOTAL = WN_LDS_D + 2 * WN_DBUF;  // 126,848 B
+constexpr int WN_PA = 2;                   // stages of look-ahead on the V fragments
 constexpr int WN_P = 5;                    // LDS-DMA pieces per wave and chunk: 4 x 5 = 20 >= the image's 18 KiB pieces
 
 // LDS-DMA of 64 x 16 bytes, hidden from the compiler (it would otherwise order this wave's later LDS reads behind a vmcnt(0) of
@@ -54,11 +60,11 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4v;
 
-template <bool HAS_RES>
+// DIAG (timing experiments only; results are wrong for != 0): 1 = no input transform, 2 = no epilogue, 3 = no MFMAs, 4 = no barriers in the loop
+template <bool HAS_RES, int DIAG = 0>
 __global__ void __launch_bounds__(256, 1)
-    conv3x3_wino_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
-                        const _Float16* __restrict__ res, _Float16* __restrict__ out, unsigned* __restrict__ sat, int cin, int cout,
-                        int flags) {
+    conv3x3_wino_kernel(const float* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
+                        const float* __restrict__ res, float* __restrict__ out, unsigned* __restrict__ sat, int cin, int cout) {
     typedef _Float16 T;
     typedef Mfma<T>::frag frag;
     constexpr int D = WN_D;
@@ -83,7 +89,7 @@ __global__ void __launch_bounds__(256, 1)
     const char* wblk = reinterpret_cast<const char*>(wu) + (size_t)(cout0 >> 5) * nst * SW_STAGE;
     const uint32_t voff0 = lane * 16;
     u32x4 ring[D][2];
-    auto load_stage = [&](u32x4(&slot)[2], const char* p) {
+    auto load_stage = [&](u32x4(&slot)[2], const char* p) __attribute__((always_inline)) {
         u32x4 l0, l1;
         asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
                      : "=&v"(l0), "=&v"(l1)
@@ -104,39 +110,38 @@ __global__ void __launch_bounds__(256, 1)
         off_a[i] = (uint32_t)irow * row_bytes + c * 16;
         dst_a[i] = id * 1024;
     }
-    auto issue_chunk = [&](int ch, int buf) {  // chunk ch -> buffer buf
+    auto issue_chunk = [&](int ch, int buf) __attribute__((always_inline)) {  // chunk ch -> buffer buf
         const char* src = abase0 + (size_t)ch * 128;
         const uint32_t dst = WN_LDS_D + buf * WN_DBUF;
 #pragma unroll
         for (int i = 0; i < WN_P; i++) glds16_asm(src + off_a[i], dst + dst_a[i]);
     };
-    if (tid < 18) reinterpret_cast<f32x4*>(smem + WN_LDS_D + (tid / 9) * WN_DBUF + WN_DZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 2 * 28 * 9; i += 256)  // the two zero areas: 28 rows of nine 16-byte slots each
+        reinterpret_cast<f32x4*>(smem + WN_LDS_D + (i / 252) * WN_DBUF + WN_DZERO)[i % 252] = f32x4{0.f, 0.f, 0.f, 0.f};
     issue_chunk(0, 0);
     issue_chunk(1, 1);  // cin >= 64: at least two chunks
 
     // ---- the transform's item: tile tid & 31 (board t >> 4, tile row (t >> 2) & 3, tile column t & 3), channel pair tid >> 5 ----
     const int tt = tid & 31, chp = tid >> 5;
-    int drow[16];  // byte offset of each patch pixel's row in a chunk image (+ the channel pair's 4 bytes); the zero row off the board
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int y = 2 * ((tt >> 2) & 3) - 1 + i, x = 2 * (tt & 3) - 1 + j;
-            const bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
-            drow[i * 4 + j] = (ok ? ((tt >> 4) * 64 + y * 8 + x) * SP : WN_DZERO) + chp * 4;
-        }
+    // The patch pixel (i, j) of the tile is image row base + 8 i + j; rows 0 / 3 and columns 0 / 3 of the patch can lie off the board
+    // (first / last tile row or column): those reads go to the zero area at the same offset.  One base register and four flags
+    // instead of sixteen row addresses.
+    const int tbase = (((tt >> 4) * 64 + (2 * ((tt >> 2) & 3) - 1) * 8 + 2 * (tt & 3) - 1) * SP) + chp * 8;
+    const int zbase = WN_DZERO + chp * 8;
+    const int tdelta = tbase - zbase;  // address = zero area + (tdelta & mask): the masks are all ones where the patch row / column is on the board
+    const int mr0 = ((tt >> 2) & 3) != 0 ? -1 : 0, mr3 = ((tt >> 2) & 3) != 3 ? -1 : 0, mc0 = (tt & 3) != 0 ? -1 : 0, mc3 = (tt & 3) != 3 ? -1 : 0;
     const int vwr = tt * WN_VP + chp * 4;  // where this item's hi pair goes inside a frequency's block (the lo pair 32 further)
     f32x2 dd[16];                          // the patch as f32, then (in place) B^T d, then B^T d B
+    float vmax = 0.0f;                     // largest |V| this thread has seen
     // kp: which half (16 channels) of the chunk; slices 0..3 read a patch row each, 4..7 do the row transform of a column,
     // 8..11 the column transform of a row and write its four frequencies.  Everything else: nothing.
-    auto transform_slice = [&](int slice, int dbase, int kp, int vbase) {
+    auto transform_slice = [&](int slice, int dbase, int kp, int vbase) __attribute__((always_inline)) {
         if (slice < 4) {
             const int i = slice;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const char* p = smem + dbase + drow[i * 4 + j] + kp * 32;
-                const f16x2v hi = *reinterpret_cast<const f16x2v*>(p), lo = *reinterpret_cast<const f16x2v*>(p + 64);
-                dd[i * 4 + j] = f32x2{(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1]};  // hi + lo is exact in f32
+                const int mask = (i == 0 ? mr0 : i == 3 ? mr3 : -1) & (j == 0 ? mc0 : j == 3 ? mc3 : -1);
+                dd[i * 4 + j] = *reinterpret_cast<const f32x2*>(smem + dbase + zbase + (tdelta & mask) + ((i * 8 + j) * SP + kp * 64));
             }
         } else if (slice < 8) {
             const int j = slice - 4;  // column j: B^T over the rows
@@ -149,11 +154,11 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
             for (int l = 0; l < 4; l++) {
                 f32x2 x = v[l];
-                // |V| can reach 4 x 65504: saturate rather than overflow (activations that large are counted as saturated already)
+                // the f16 range is left HERE in this tower (activations are f32): saturate rather than overflow, and count it
+                vmax = fmaxf(fmaxf(vmax, fabsf(x[0])), fabsf(x[1]));  // one v_max3: checked once, at the end
                 x = __builtin_elementwise_min(__builtin_elementwise_max(x, f32x2{-65504.0f, -65504.0f}), f32x2{65504.0f, 65504.0f});
-                f16x2v hi, lo;
-                hi[0] = (T)x[0], hi[1] = (T)x[1];
-                lo[0] = (T)(x[0] - (float)hi[0]), lo[1] = (T)(x[1] - (float)hi[1]);
+                const f16x2v hi = __builtin_convertvector(x, f16x2v);
+                const f16x2v lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), f16x2v);
                 char* q = smem + vbase + (i * 4 + l) * WN_VF + vwr;
                 *reinterpret_cast<f16x2v*>(q) = hi;
                 *reinterpret_cast<f16x2v*>(q + 32) = lo;
@@ -176,17 +181,23 @@ __global__ void __launch_bounds__(256, 1)
     const int vrd = r * WN_VP + h * 16;  // this lane's fragment inside a frequency's block: tile r, channels 8 h .. 8 h + 7 (lo 32 further)
     // One k-step: 16 stages on the V image at `vimg`, with the transform of the NEXT k-step (chunk image at `dbase`, half kp, into
     // the other V image) sliced in between.  JB: the stage's index inside the chunk body (0 or 16), which fixes the wait counts.
-    auto kstep = [&](int s0, int vimg, int dbase, int kp, int vnext, auto jb_tag) {
+    auto kstep = [&](int s0, int vimg, int dbase, int kp, int vnext, auto jb_tag) __attribute__((always_inline)) {
         constexpr int JB = decltype(jb_tag)::value;
-        frag vh[2], vl[2];
-        vh[0] = *reinterpret_cast<const frag*>(smem + vimg + vrd);
-        vl[0] = *reinterpret_cast<const frag*>(smem + vimg + vrd + 32);
+        // WN_PA stages of look-ahead on the V fragments (never across the k-step: the next image is being written): an LDS read
+        // queues behind the transform slices' reads and writes of this wave (the LDS queue is in order), so one stage is not enough
+        constexpr int PA = WN_PA, PR = PA + 1;
+        frag vh[PR], vl[PR];
+#pragma unroll
+        for (int q = 0; q < PA; q++) {
+            vh[q] = *reinterpret_cast<const frag*>(smem + vimg + q * WN_VF + vrd);
+            vl[q] = *reinterpret_cast<const frag*>(smem + vimg + q * WN_VF + vrd + 32);
+        }
 #pragma unroll
         for (int f = 0; f < 16; f++) {
-            const int cur = f & 1, nxt = cur ^ 1;
-            if (f + 1 < 16) {  // one stage of look-ahead on the V fragments (never across the k-step: the next image is being written)
-                vh[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + 1) * WN_VF + vrd);
-                vl[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + 1) * WN_VF + vrd + 32);
+            const int cur = f % PR, nxt = (f + PA) % PR;
+            if (f + PA < 16) {
+                vh[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd);
+                vl[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd + 32);
             }
             // all but the youngest 2 (D - 1) ring loads have returned -- plus, for the D stages whose own loads went out before this
             // body's LDS-DMA (issued between its stages 15 and 16), those WN_P younger DMA instructions
@@ -199,122 +210,150 @@ __global__ void __launch_bounds__(256, 1)
             }
             const frag uh = __builtin_bit_cast(frag, ring[f % D][0]);
             const frag ul = __builtin_bit_cast(frag, ring[f % D][1]);
-            Mfma<T>::mac(ul, vh[cur], acc[f]);
-            Mfma<T>::mac(uh, vl[cur], acc[f]);
-            Mfma<T>::mac(uh, vh[cur], acc[f]);
+            if constexpr (DIAG != 3) {
+                Mfma<T>::mac(ul, vh[cur], acc[f]);
+                Mfma<T>::mac(uh, vl[cur], acc[f]);
+                Mfma<T>::mac(uh, vh[cur], acc[f]);
+            } else {
+                acc[f][0] += (float)ul[0] + (float)uh[0] + (float)vh[cur][0] + (float)vl[cur][0];
+            }
             {  // refill D stages ahead; past the layer's end the last stage is re-read (the count of loads in flight stays fixed)
                 const int sn = min(s0 + f + D, nst - 1);
                 load_stage(ring[f % D], wblk + (size_t)sn * SW_STAGE);
             }
-            transform_slice(f, dbase, kp, vnext);
+            if constexpr (DIAG != 1) transform_slice(f, dbase, kp, vnext);
         }
     };
     for (int c = 0; c < nch; c++) {
         const int dcur = WN_LDS_D + (c & 1) * WN_DBUF, dnext = WN_LDS_D + ((c + 1) & 1) * WN_DBUF;
         // k-step 2c on image 0; meanwhile V of k-step 2c + 1 (the chunk's second half) -> image 1
         kstep(c * 32, 0, dcur, 1, WN_VIMG, std::integral_constant<int, 0>{});
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // image 1 is complete, image 0 and chunk c are free
+        if constexpr (DIAG != 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // image 1 is complete, image 0 and chunk c are free
         issue_chunk(min(c + 2, nch - 1), c & 1);                           // -> the buffer chunk c was in (past the end: a re-read nobody uses)
         // k-step 2c + 1 on image 1; meanwhile V of k-step 2c + 2 (the next chunk's first half) -> image 0
         kstep(c * 32 + 16, WN_VIMG, dnext, 0, 0, std::integral_constant<int, 16>{});
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (DIAG != 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // the ring's last refills (nobody reads them) and the last DMA.  The ring's registers are operands of the wait: to the compiler
     // they are free from their last MFMA on, and it would park epilogue values in them while the loads are still on their way
-    static_assert(D == 8, "the drain below names every ring slot");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[1][0]), "+v"(ring[1][1]), "+v"(ring[2][0]), "+v"(ring[2][1]), "+v"(ring[3][0]),
-                   "+v"(ring[3][1]), "+v"(ring[4][0]), "+v"(ring[4][1]), "+v"(ring[5][0]), "+v"(ring[5][1]), "+v"(ring[6][0]), "+v"(ring[6][1]),
-                   "+v"(ring[7][0]), "+v"(ring[7][1])
-                 :
-                 : "memory");
-
-    // ---- output transform: per lane and accumulator element, Y = A^T M A over the 16 frequencies (f = 4 i + l) ----
-    // A^T = [1 1 1 0; 0 1 -1 -1]: Z[i][0] = M[i][0] + M[i][1] + M[i][2], Z[i][1] = M[i][1] - M[i][2] - M[i][3], then the same over i.
-    f32x16 y[4];  // y[2 p + q]: output pixel (2 ty + p, 2 tx + q) of the lane's tile
+    __builtin_amdgcn_sched_barrier(0);  // nothing of the epilogue above the drain: the ring's 64 registers are still taken there
 #pragma unroll
-    for (int q = 0; q < 2; q++) {  // one output column at a time: 64 registers of Z instead of 128
-        f32x16 z[4];
+    for (int d = 0; d < D; d++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[d][0]), "+v"(ring[d][1])::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DIAG == 2) {
+        float sum = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; i++) z[i] = q == 0 ? acc[i * 4] + acc[i * 4 + 1] + acc[i * 4 + 2] : acc[i * 4 + 1] - acc[i * 4 + 2] - acc[i * 4 + 3];
-        y[q] = z[0] + z[1] + z[2];
-        y[2 + q] = z[1] - z[2] - z[3];
+        for (int f = 0; f < 16; f++) sum += acc[f][0] + acc[f][5];
+        if (sum == 12345.678f) out[tid] = sum;
+        return;
     }
-    // ---- epilogue: lane (tile r, half h) holds couts cout0 + 8 g + 4 h + i (g, i < 4) of the tile's four pixels ----
-    const int board = r >> 4, ty = (r >> 2) & 3, tx = r & 3;
-    const size_t orow = (size_t)cout * 2;  // f16 elements per row of `res` / `out`
-    const int ocol = (cout0 >> 5) * 64 + h * 4;  // hi of couts cout0 + 4 h ..; the lo values 32 elements further; + 8 g per group
-    f32x4 bv[4], dv[4];
+    // ---- epilogue ----
+    // Everything the epilogue derives from the lane index is derived from an opaque copy made HERE: computed ahead of the loop (where
+    // the compiler would hoist it) it would stay live through the loop, which has no register to spare.
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int er = elane & 31, eh = elane >> 5;
+    // Output transform Y = A^T M A over the 16 frequencies f = 4 i + l (A^T = [1 1 1 0; 0 1 -1 -1]: Z[i][0] = M[i][0] + M[i][1] + M[i][2],
+    // Z[i][1] = M[i][1] - M[i][2] - M[i][3], then the same over i), four accumulator elements (couts 8 g + 4 h ..) at a time, each
+    // result straight into the transpose: lane (tile r, half h) holds couts 8 g + 4 h + i of its tile's four pixels, the wave's 128
+    // pixels x 32 couts go through LDS as f32 (the V images are free now: 16 KiB per wave, 16-byte slots XOR-swizzled by the pixel) and
+    // come back as (pixel, 8 consecutive couts) per lane -- whole 64-byte runs per store instruction, the direct kernel's epilogue.
+    // (Written straight from the accumulator layout the output is 32 eight-byte stores per lane: 11.6 of 48 us.)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the V images
+    char* stage = smem + wave * 16384;
+    const int board = er >> 4, ty = (er >> 2) & 3, tx = er & 3;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        bv[g] = *reinterpret_cast<const f32x4*>(bias + cout0 + g * 8 + h * 4);
-        dv[g] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + g * 8 + h * 4);
-    }
+        __builtin_amdgcn_sched_barrier(0);  // one group's 64 accumulator elements in VGPRs at a time (hoisted together they spill)
+        f32x4 m[16];
 #pragma unroll
-    for (int pq = 0; pq < 4; pq++) {
-        const size_t row = (size_t)row0 + board * 64 + (2 * ty + (pq >> 1)) * 8 + 2 * tx + (pq & 1);
-        f16x4v sh[4], sl[4];
-        if (HAS_RES) {
+        for (int f = 0; f < 16; f++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                sh[g] = *reinterpret_cast<const f16x4v*>(res + row * orow + ocol + g * 8);
-                sl[g] = *reinterpret_cast<const f16x4v*>(res + row * orow + ocol + g * 8 + 32);
-            }
+            for (int i = 0; i < 4; i++) m[f][i] = acc[f][g * 4 + i];
+        f32x4 z[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            z[i][0] = m[i * 4] + m[i * 4 + 1] + m[i * 4 + 2];
+            z[i][1] = m[i * 4 + 1] - m[i * 4 + 2] - m[i * 4 + 3];
         }
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int g = half * 2 + q;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    float x = __builtin_fmaf(y[pq][g * 4 + i], dv[g][i], bv[g][i]);  // the inverse weight scale is a power of two: exact
-                    if (HAS_RES) x = x + ((float)sh[g][i] + (float)sl[g][i]);
-                    v[q * 4 + i] = x > 0.0f ? x : 0.0f;
-                }
-            }
-            if (flags & CONV_OUT_F32) {  // the tower's last layer: plain f32 rows for the head kernels
-                float* of = reinterpret_cast<float*>(out) + row * (size_t)cout + cout0 + h * 4;
-#pragma unroll
-                for (int q = 0; q < 2; q++) *reinterpret_cast<f32x4*>(of + (half * 2 + q) * 8) = f32x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
-            } else {
-                note_saturation(v, true, sat);
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int g = half * 2 + q;
-                    f16x4v hi, lo;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float yc = v[q * 4 + i] < 65504.0f ? v[q * 4 + i] : 65504.0f;
-                        hi[i] = (T)yc;
-                        lo[i] = (T)(yc - (float)hi[i]);
-                    }
-                    *reinterpret_cast<f16x4v*>(out + row * orow + ocol + g * 8) = hi;
-                    *reinterpret_cast<f16x4v*>(out + row * orow + ocol + g * 8 + 32) = lo;
-                }
-            }
+        for (int pq = 0; pq < 4; pq++) {
+            const int q = pq & 1;
+            const f32x4 yv = (pq >> 1) == 0 ? z[0][q] + z[1][q] + z[2][q] : z[1][q] - z[2][q] - z[3][q];
+            const int px = board * 64 + (2 * ty + (pq >> 1)) * 8 + 2 * tx + q;  // pixel row inside the workgroup's 128
+            *reinterpret_cast<f32x4*>(stage + px * 128 + (((g * 2 + eh) ^ (px & 7)) << 4)) = yv;
         }
     }
+    // the skip rows of the lane's eight (pixel, 8 couts) pieces of the final layout: requested behind the output transform (whose temporaries leave no room for these 64 registers), used behind the transpose
+    f32x4 skip[8][2];
+    if (HAS_RES) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const size_t at = ((size_t)row0 + k * 16 + (elane >> 2)) * (size_t)cout + cout0 + (elane & 3) * 8;
+            skip[k][0] = *reinterpret_cast<const f32x4*>(res + at);
+            skip[k][1] = *reinterpret_cast<const f32x4*>(res + at + 4);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a wave reads back only what it wrote itself
+    const int cg = elane & 3;               // this lane's 8 couts: 8 cg .. 8 cg + 7 of the wave's 32
+    f32x4 bias8[2], ds8[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        bias8[q] = *reinterpret_cast<const f32x4*>(bias + cout0 + cg * 8 + q * 4);
+        ds8[q] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cg * 8 + q * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int px = k * 16 + (elane >> 2);
+        const size_t at = ((size_t)row0 + px) * (size_t)cout + cout0 + cg * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(stage + px * 128 + (((2 * cg) ^ (px & 7)) << 4));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(stage + px * 128 + (((2 * cg + 1) ^ (px & 7)) << 4));
+        f32x4 v0, v1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // the inverse weight scale is a power of two: the product is exact, the fma rounds once
+            float x0 = __builtin_fmaf(a[j], ds8[0][j], bias8[0][j]), x1 = __builtin_fmaf(b[j], ds8[1][j], bias8[1][j]);
+            if (HAS_RES) x0 = x0 + skip[k][0][j], x1 = x1 + skip[k][1][j];
+            v0[j] = x0 > 0.0f ? x0 : 0.0f, v1[j] = x1 > 0.0f ? x1 : 0.0f;
+        }
+        __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(out + at));
+        __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(out + at) + 1);
+    }
+    if (vmax > 65504.0f) atomicAdd(sat, 1u);  // a transformed input left the f16 range somewhere in this thread's share
 }
 
 bool wino_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S) {
     return S == 8 && cin >= 64 && cin % 32 == 0 && cout % 128 == 0 && bpad % 2 == 0;
 }
 
-void launch_conv3x3_wino(const void* in, const void* wu, const float* bias, const void* res, void* out, uint32_t bpad, uint32_t cin,
-                         uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, int flags, unsigned* sat) {
+void launch_conv3x3_wino(const float* in, const void* wu, const float* bias, const float* res, float* out, uint32_t bpad, uint32_t cin,
+                         uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat) {
     typedef _Float16 H;
     const dim3 grid((bpad / 2) * (cout / 128));
+    static const int diag = getenv("CATTUS_WINO_DIAG") ? atoi(getenv("CATTUS_WINO_DIAG")) : 0;
+#define CATTUS_WINO_DIAG_LAUNCH(DV)                                                                                                            \
+    if (diag == DV) {                                                                                                                          \
+        hipExtLaunchKernelGGL((conv3x3_wino_kernel<true, DV>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, in,                    \
+                              (const H*)wu, bias, res ? res : in, out, sat, (int)cin, (int)cout);                                              \
+        return;                                                                                                                                \
+    }
+    CATTUS_WINO_DIAG_LAUNCH(1)
+    CATTUS_WINO_DIAG_LAUNCH(2)
+    CATTUS_WINO_DIAG_LAUNCH(3)
+    CATTUS_WINO_DIAG_LAUNCH(4)
+#undef CATTUS_WINO_DIAG_LAUNCH
     if (res)
-        hipExtLaunchKernelGGL((conv3x3_wino_kernel<true>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, (const H*)in, (const H*)wu,
-                              bias, (const H*)res, (H*)out, sat, (int)cin, (int)cout, flags);
+        hipExtLaunchKernelGGL((conv3x3_wino_kernel<true>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, in, (const H*)wu, bias, res, out,
+                              sat, (int)cin, (int)cout);
     else
-        hipExtLaunchKernelGGL((conv3x3_wino_kernel<false>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, (const H*)in, (const H*)wu,
-                              bias, (const H*)res, (H*)out, sat, (int)cin, (int)cout, flags);
+        hipExtLaunchKernelGGL((conv3x3_wino_kernel<false>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, in, (const H*)wu, bias, res, out,
+                              sat, (int)cin, (int)cout);
 }
 
 hipError_t prepare_wino() {
+    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, 1>), reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, 2>),
+                           reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, 3>), reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, 4>)})
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_TOTAL);
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_TOTAL);
     const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_TOTAL);
     return err != hipSuccess ? err : e2;

@@ -50,6 +50,7 @@ ABI_SYMBOLS = [
     "cattus_hip_last_error",
     "cattus_hip_version",
     "cattus_hip_runtime_note",
+    "cattus_hip_tower_kernel",
 ]
 
 
@@ -127,9 +128,12 @@ def load_library():
     L.cattus_hip_last_error.restype = C.c_char_p
     L.cattus_hip_version.restype = C.c_char_p
     L.cattus_hip_runtime_note.restype = C.c_char_p
+    L.cattus_hip_tower_kernel.argtypes = [vp]
+    L.cattus_hip_tower_kernel.restype = C.c_char_p
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("cattus_hip_last_error", "cattus_hip_version", "cattus_hip_runtime_note", "cattus_hip_host_alloc"):
+        if fn.restype is C.c_int and name not in ("cattus_hip_last_error", "cattus_hip_version", "cattus_hip_runtime_note", "cattus_hip_host_alloc",
+                                                   "cattus_hip_tower_kernel"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -279,6 +283,10 @@ class HipEvaluator:
         s = Stats()
         _check(self._lib.cattus_hip_stats(self._h, C.byref(s)))
         return {name: getattr(s, name) for name, _ in Stats._fields_}
+
+    def tower_kernel(self) -> str:
+        """Name of the kernel that runs this evaluator's tower."""
+        return self._lib.cattus_hip_tower_kernel(self._h).decode()
 
     def mfma_sustained(self, seconds: float = 1.0) -> float:
         """TFLOP/s the device's matrix pipe sustains on back-to-back MFMAs of this evaluator's tower kind (diagnostic)."""

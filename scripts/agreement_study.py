@@ -2,6 +2,7 @@
 """A reduced-cost tower (f16x2 or bf16) against the exact-f32 one at search level, on a larger sample than the GPU test's
 (tests/test_search_parity_gpu.py: 16 games):
     python scripts/agreement_study.py [GAMES=128] [PLIES=16] [SIMS=800] [chess20x256|hex7_6x64] [DTYPES=f16x2,bf16]
+(a dtype "f16x2w" is the f16x2 tower forced into its Winograd form, which an evaluator of this study's small batches would not pick)
 f32 plays GAMES games of chess 20x256 (or hex7 6x64, BASELINE config 2's net) (random 2-ply openings, greedy, noise off)
 for PLIES searched plies; each dtype under test searches the same positions (teacher-forced, trees carried over).
 Prints one JSON object per dtype."""
@@ -37,12 +38,18 @@ with HipEvaluator(blob, batch_size=games, plane_words=words, dtype="f32", flush_
     ta = ag.run_traces(game, cfg, sp.Net.hip_batched(ev32), opens, 2, plies)
 t1f = time.time()
 lines = [op + [chosen for chosen, _ in t] for op, t in zip(opens, ta)]
+import os  # noqa: E402
+
 for dtype in dtypes:
     t1 = time.time()
-    with HipEvaluator(blob, batch_size=games, plane_words=words, dtype=dtype, flush_us=100) as evx:
+    os.environ.pop("CATTUS_WINOGRAD", None)
+    if dtype == "f16x2w":
+        os.environ["CATTUS_WINOGRAD"] = "1"
+    with HipEvaluator(blob, batch_size=games, plane_words=words, dtype=dtype.rstrip("w"), flush_us=100) as evx:
+        tower = evx.tower_kernel()
         tb = ag.run_traces(game, cfg, sp.Net.hip_batched(evx), lines, 2, plies)
     t2 = time.time()
     res = ag.compare_traces(ta, tb)
-    res.update(net=which, dtype=dtype, games=games, sims_per_move=sims, searched_plies_per_game=plies, opening_plies=2,
+    res.update(net=which, dtype=dtype, tower_kernel=tower, games=games, sims_per_move=sims, searched_plies_per_game=plies, opening_plies=2,
                f32_seconds=round(t1f - t0, 1), seconds=round(t2 - t1, 1))
     print(json.dumps(res), flush=True)

@@ -90,6 +90,57 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const char* __restrict__ u
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
+// Two waves per SIMD: 8 waves per workgroup, wave (w & 3) = cout block, (w >> 2) = which half of the 16 frequencies it accumulates
+// (8 accumulators = 128 registers; the output transform would exchange partial sums through LDS once per layer).
+template <int D>
+__global__ void __launch_bounds__(512, 1) wino8_kernel(const char* __restrict__ u, int layers, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2 * V_BYTES / 4; i += 512) reinterpret_cast<float*>(smem)[i] = 0.001f * (i & 7);
+    __syncthreads();
+    const int cblk = (blockIdx.x & 1) * 4 + (wave & 3), fh = wave >> 2;
+    const char* vrow = smem + (lane & 31) * 144 + (lane >> 5) * 16;
+    floatx16 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; f++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[f][j] = 0.0f;
+    const uint32_t voff = lane * 16;
+    u32x4 ring[D][2];
+    u32x4 l0, l1;
+    constexpr int ST = KSTEPS * 8;  // this wave's stages per layer
+    for (int layer = 0; layer < layers; layer++) {
+        // stage (k, f') of this wave is global stage k * 16 + fh * 8 + f'
+        const char* wp = u + ((size_t)layer * 8 + cblk) * STAGES * STAGE_BYTES + (size_t)fh * 8 * STAGE_BYTES;
+#pragma unroll
+        for (int d = 0; d < D; d++) LOAD_STAGE(d, wp + (size_t)((d >> 3) * 16 + (d & 7)) * STAGE_BYTES);
+        for (int k = 0; k < KSTEPS; k++) {
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                const int s = k * 8 + f;
+                asm volatile("" ::: "memory");
+                const half8 vh = *reinterpret_cast<const half8*>(vrow + (fh * 8 + f) * 33 * 144 + (k & 1) * 32);
+                const half8 vl = *reinterpret_cast<const half8*>(vrow + (fh * 8 + f) * 33 * 144 + (k & 1) * 32 + 64);
+                u32x4 r0 = ring[f % D][0], r1 = ring[f % D][1];
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(2 * (D - 1)));
+                const half8 uh = __builtin_bit_cast(half8, r0), ul = __builtin_bit_cast(half8, r1);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vl, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vh, acc[f], 0, 0, 0);
+                const int sn = s + D < ST ? s + D : ST - 1;
+                LOAD_STAGE(f % D, wp + (size_t)((sn >> 3) * 16 + (sn & 7)) * STAGE_BYTES);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 8; f++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) sum += acc[f][j];
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = sum;
+}
+
 // The direct form's stage on the same harness: 4 U fragments from L2 + 4 V fragments from LDS per 12 MFMAs, 144 stages per layer.
 template <int D>
 __global__ void __launch_bounds__(256, 1) direct_kernel(const char* __restrict__ u, int layers, float* __restrict__ out) {
@@ -159,14 +210,14 @@ __global__ void __launch_bounds__(256, 1) direct_kernel(const char* __restrict__
 }
 
 template <typename K>
-static double run(K kernel, const char* what, const char* dU, int grid, int layers, float* dOut, int lds, double mfma_floor_cycles) {
+static double run(K kernel, const char* what, const char* dU, int grid, int layers, float* dOut, int lds, double mfma_floor_cycles, int threads = 256) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 6; rep++) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, 0, dU, layers, dOut);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, 0, dU, layers, dOut);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -187,7 +238,7 @@ int main(int argc, char** argv) {
     char* dU;
     float* dOut;
     hipMalloc(&dU, bytes);
-    hipMalloc(&dOut, (size_t)grid * 256 * 4);
+    hipMalloc(&dOut, (size_t)grid * 512 * 4);
     hipMemcpy(dU, h.data(), bytes, hipMemcpyHostToDevice);
     const int lds = 2 * V_BYTES;
     printf("U: %.1f MB per layer, %d layers; V image %d B per tile block and chunk\n", 8.0 * STAGES * STAGE_BYTES / 1e6, layers, V_BYTES);
@@ -197,6 +248,7 @@ int main(int argc, char** argv) {
     run(wino_kernel<16, 0, false>, "winograd, waves share V (4 cout blocks), ring 16", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<8, 0, true>, "winograd, waves 2 tile blocks x 2 cout blocks, ring 8", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<16, 0, true>, "winograd, waves 2 tile blocks x 2 cout blocks, ring 16", dU, grid, layers, dOut, lds, wf);
+    run(wino8_kernel<8>, "winograd, 8 waves (2 per SIMD, 8 frequencies each), share V, ring 8", dU, grid, layers, dOut, lds, wf, 512);
     run(wino_kernel<16, 1, false>, "winograd operand streams alone (no MFMA), share V, ring 16", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<16, 1, true>, "winograd operand streams alone (no MFMA), 2 x 2, ring 16", dU, grid, layers, dOut, lds, wf);
     return 0;

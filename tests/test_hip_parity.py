@@ -643,3 +643,73 @@ def test_device_pointer_entry_points_and_lanes_agree_with_host_entry_point():
         torch.cuda.default_stream(dev).synchronize()
         assert (got.cpu().numpy() == want_p).all()
         assert ev.lane_stream(0) != 0 and ev.lane_stream(0) != ev.lane_stream(1)
+
+
+# ---- the split tower in Winograd F(2x2, 3x3) form (kernels_wino.hip): f16x2 evaluators of 8x8-board networks with a multiple of 128
+# filters and max_batch >= 192 ----
+WINO_POLICY_ATOL_VS_F64, WINO_VALUE_ATOL_VS_F64 = 1.5e-6, 5e-7  # measured 5.1e-7 / 1.3e-7 (the direct split tower: 6.3e-7 / 2.1e-7)
+
+
+def test_winograd_tower_within_the_reference_tolerance_and_batch_independent(monkeypatch):
+    """chess 20x256 (the reference-made fixture): with max_batch >= 192 the f16x2 tower runs its 40 layers behind the stem in
+    Winograd form -- 2.25x fewer MFMAs, operands transformed in f32 / float64 and split into f16 pairs, f32 activations between the
+    layers.  Inside the reference's cross-runtime bar (training/tests/test_net_output.py:28-33), as close to the reference's float64
+    run as the direct split tower, the same bits whatever the batch a leaf comes in, and selected by max_batch alone."""
+    d, blob, z = blob_for("chess_20x256")
+    planes = z["planes"]
+    rep = np.concatenate([planes] * 50)[:197]
+    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
+        assert ev.tower_kernel() == "conv3x3_wino_kernel"
+        p, v = ev.eval(planes)
+        pr, vr = ev.eval(rep)
+        assert ev.stats()["saturated"] == 0
+    assert outputs_equal_ref_tol(p, v, z["policy"], z["value"])
+    assert np.abs(p - z["policy_f64"]).max() <= WINO_POLICY_ATOL_VS_F64 and np.abs(v - z["value_f64"]).max() <= WINO_VALUE_ATOL_VS_F64
+    for i in range(len(rep)):  # a leaf's bits do not depend on the batch or the slot
+        assert (pr[i] == p[i % len(planes)]).all() and vr[i] == v[i % len(planes)]
+    with HipEvaluator(blob, batch_size=128, plane_words=1, dtype="f16x2") as ev:
+        assert ev.tower_kernel() == "conv3x3_splitw_kernel"  # small batches: the direct kernels' small tiles
+    monkeypatch.setenv("CATTUS_WINOGRAD", "0")
+    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
+        assert ev.tower_kernel() == "conv3x3_splitw_kernel"
+        pd, vd = ev.eval(planes)
+    assert np.abs(p - pd).max() < 2e-6 and np.abs(v - vd).max() < 1e-6  # the two forms of the same tower
+
+
+@pytest.mark.parametrize("net,n,bound", [("20x256", 256, (3e-6, 1e-6)), ("40x384", 512, (1.2e-5, 2e-6))])
+def test_winograd_tower_tracks_the_f32_tower_at_full_size(net, n, bound):
+    """BASELINE configs 3 and 5 at full size in Winograd form against the bit-exact f32 tower, under the bounds the direct split
+    tower is held to (measured on 256 / 512 leaves: 1.1e-6 / 3.1e-7 and 3.5e-6 / 8e-7)."""
+    blocks, filters = (20, 256) if net == "20x256" else (40, 384)
+    d = NetDesc(**CHESS, blocks=blocks, filters=filters, vhc=8, phc=8)
+    blob = seeded_blob(d, 2 if net == "20x256" else 3)
+    planes = synth.random_chess_planes(n, 2 if net == "20x256" else 3)
+    rows = np.random.default_rng(1).choice(n, size=24, replace=False)
+    with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f32") as ev:
+        want_p, want_v = ev.eval(planes[rows])
+    with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f16x2") as ev:
+        assert ev.tower_kernel() == "conv3x3_wino_kernel"
+        got_p, got_v = ev.eval(planes)
+    assert np.isfinite(got_p).all() and np.isfinite(got_v).all()
+    assert np.abs(got_p[rows] - want_p).max() <= bound[0] and np.abs(got_v[rows] - want_v).max() <= bound[1]
+
+
+def test_winograd_tower_counts_inputs_that_leave_the_f16_range():
+    """The Winograd tower keeps f32 activations; what leaves the f16 range there is a TRANSFORMED input (up to four times an
+    activation).  It is clamped and counted like the direct tower's activations: 0 for a BatchNorm scale of 200, > 0 for 1e5."""
+    from cattus_amd.weights import pack_tensors, seeded_tensors
+
+    d = NetDesc(**CHESS, blocks=2, filters=128, vhc=8, phc=8)
+    planes = synth.random_chess_planes(9, 4)
+    for scale, saturates in ((200.0, False), (1e5, True)):
+        t = seeded_tensors(d, 6)
+        t["_conv1._bn.weight"] = t["_conv1._bn.weight"] * np.float32(scale)
+        blob = pack_tensors(d, t)
+        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
+            assert ev.tower_kernel() == "conv3x3_wino_kernel"
+            p, v = ev.eval(planes)
+            assert (ev.stats()["saturated"] > 0) == saturates
+        assert np.isfinite(p).all() and np.isfinite(v).all()
+        if not saturates:
+            want_p, want_v = oracle.OracleNet(blob).forward(planes)
+            np.testing.assert_allclose(p, want_p, rtol=2e-5, atol=2e-5 * np.abs(want_p).max())

@@ -62,6 +62,8 @@ def test_no_compiler_instruction_touches_a_register_with_an_asm_load_in_flight()
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    p = subprocess.run([sys.executable, str(root / "scripts" / "audit_inflight_regs.py")], capture_output=True, text=True, timeout=600)
+    csrc = root / "cattus_amd" / "csrc"
+    p = subprocess.run([sys.executable, str(root / "scripts" / "audit_inflight_regs.py"), str(csrc / "kernels_t64s.hip"), str(csrc / "kernels_wino.hip")],
+                       capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "4 kernels with asm statements audited" in p.stderr
+    assert "kernels_t64s.hip: 4 kernels with asm statements audited" in p.stderr and "kernels_wino.hip:" in p.stderr
