@@ -55,15 +55,17 @@ def mfma_terms(dtype: str, kernel: str) -> float:
     return MFMA_TERMS[dtype] * (16.0 / 36.0 if kernel == "conv3x3_wino_kernel" else 1.0)
 
 DTYPE_NOTE = {
-    "f16x2": "split precision: activations and weights as pairs of f16 values (22 significant bits), three f16 MFMA terms per product, "
-             "f32 accumulation, f32 heads; inside the reference's cross-runtime tolerance (training/tests/test_net_output.py:28-33)",
+    "f16x2": "split precision: operands as pairs of f16 values (22 significant bits), three f16 MFMA terms per product, f32 accumulation, "
+             "f32 heads; inside the reference's cross-runtime tolerance (training/tests/test_net_output.py:28-33).  At batch >= 192 on 8x8 "
+             "boards the tower runs in Winograd F(2x2,3x3) form (roofline.kernel says which): 2.25x fewer MFMAs, same tolerance, the f32 "
+             "search's visit counts in 2,048 of 2,048 searches",
     "bf16": "bf16 operands, f32 accumulation: throughput mode, 8 significant bits, outside the reference's tolerance",
     "f16": "single-term f16 operands (weights pre-scaled per output channel), f32 accumulation, f32 heads: throughput mode, 11 significant "
            "bits, outside the reference's tolerance; 99.4 % of the f32 search's moves (bf16: 95 %)",
     "f32": "exact-f32 MFMA tower (v_mfma_f32_32x32x2_f32): bit-identical to the CPU oracle",
 }
 # node-evals/s one GPU sustains per dtype (sizes the bounded self-play samples; measured round 3)
-EVAL_CAPACITY = {"f16x2": 135e3, "bf16": 330e3, "f16": 290e3, "f32": 44e3}
+EVAL_CAPACITY = {"f16x2": 150e3, "bf16": 330e3, "f16": 290e3, "f32": 44e3}
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on

@@ -30,8 +30,6 @@
 
 #include <hip/hip_ext.h>
 
-#include <cstdlib>
-
 namespace cattus {
 
 constexpr int WN_D = 8;                    // U stages in flight per wave (16 registers... 8 stages x 2 fragments x 4 VGPRs = 64)
@@ -60,8 +58,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4v;
 
-// DIAG (timing experiments only; results are wrong for != 0): 1 = no input transform, 2 = no epilogue, 3 = no MFMAs, 4 = no barriers in the loop
-template <bool HAS_RES, int DIAG = 0>
+template <bool HAS_RES>
 __global__ void __launch_bounds__(256, 1)
     conv3x3_wino_kernel(const float* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
                         const float* __restrict__ res, float* __restrict__ out, unsigned* __restrict__ sat, int cin, int cout) {
@@ -210,29 +207,25 @@ __global__ void __launch_bounds__(256, 1)
             }
             const frag uh = __builtin_bit_cast(frag, ring[f % D][0]);
             const frag ul = __builtin_bit_cast(frag, ring[f % D][1]);
-            if constexpr (DIAG != 3) {
-                Mfma<T>::mac(ul, vh[cur], acc[f]);
-                Mfma<T>::mac(uh, vl[cur], acc[f]);
-                Mfma<T>::mac(uh, vh[cur], acc[f]);
-            } else {
-                acc[f][0] += (float)ul[0] + (float)uh[0] + (float)vh[cur][0] + (float)vl[cur][0];
-            }
+            Mfma<T>::mac(ul, vh[cur], acc[f]);
+            Mfma<T>::mac(uh, vl[cur], acc[f]);
+            Mfma<T>::mac(uh, vh[cur], acc[f]);
             {  // refill D stages ahead; past the layer's end the last stage is re-read (the count of loads in flight stays fixed)
                 const int sn = min(s0 + f + D, nst - 1);
                 load_stage(ring[f % D], wblk + (size_t)sn * SW_STAGE);
             }
-            if constexpr (DIAG != 1) transform_slice(f, dbase, kp, vnext);
+            transform_slice(f, dbase, kp, vnext);
         }
     };
     for (int c = 0; c < nch; c++) {
         const int dcur = WN_LDS_D + (c & 1) * WN_DBUF, dnext = WN_LDS_D + ((c + 1) & 1) * WN_DBUF;
         // k-step 2c on image 0; meanwhile V of k-step 2c + 1 (the chunk's second half) -> image 1
         kstep(c * 32, 0, dcur, 1, WN_VIMG, std::integral_constant<int, 0>{});
-        if constexpr (DIAG != 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // image 1 is complete, image 0 and chunk c are free
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // image 1 is complete, image 0 and chunk c are free
         issue_chunk(min(c + 2, nch - 1), c & 1);                           // -> the buffer chunk c was in (past the end: a re-read nobody uses)
         // k-step 2c + 1 on image 1; meanwhile V of k-step 2c + 2 (the next chunk's first half) -> image 0
         kstep(c * 32 + 16, WN_VIMG, dnext, 0, 0, std::integral_constant<int, 16>{});
-        if constexpr (DIAG != 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // the ring's last refills (nobody reads them) and the last DMA.  The ring's registers are operands of the wait: to the compiler
     // they are free from their last MFMA on, and it would park epilogue values in them while the loads are still on their way
@@ -240,13 +233,6 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
     for (int d = 0; d < D; d++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[d][0]), "+v"(ring[d][1])::"memory");
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DIAG == 2) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int f = 0; f < 16; f++) sum += acc[f][0] + acc[f][5];
-        if (sum == 12345.678f) out[tid] = sum;
-        return;
-    }
     // ---- epilogue ----
     // Everything the epilogue derives from the lane index is derived from an opaque copy made HERE: computed ahead of the loop (where
     // the compiler would hoist it) it would stay live through the loop, which has no register to spare.
@@ -262,14 +248,15 @@ __global__ void __launch_bounds__(256, 1)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the V images
     char* stage = smem + wave * 16384;
     const int board = er >> 4, ty = (er >> 2) & 3, tx = er & 3;
+    // four accumulator elements (couts 8 g + 4 h ..) of every frequency at a time, each read out of its AGPR by an asm statement:
+    // left to itself the compiler copies all sixteen 16-register accumulators into VGPRs at once and spills
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        __builtin_amdgcn_sched_barrier(0);  // one group's 64 accumulator elements in VGPRs at a time (hoisted together they spill)
         f32x4 m[16];
 #pragma unroll
         for (int f = 0; f < 16; f++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) m[f][i] = acc[f][g * 4 + i];
+            for (int i = 0; i < 4; i++) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[f][i]) : "a"(acc[f][g * 4 + i]));
         f32x4 z[4][2];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -330,18 +317,6 @@ void launch_conv3x3_wino(const float* in, const void* wu, const float* bias, con
                          uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat) {
     typedef _Float16 H;
     const dim3 grid((bpad / 2) * (cout / 128));
-    static const int diag = getenv("CATTUS_WINO_DIAG") ? atoi(getenv("CATTUS_WINO_DIAG")) : 0;
-#define CATTUS_WINO_DIAG_LAUNCH(DV)                                                                                                            \
-    if (diag == DV) {                                                                                                                          \
-        hipExtLaunchKernelGGL((conv3x3_wino_kernel<true, DV>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, in,                    \
-                              (const H*)wu, bias, res ? res : in, out, sat, (int)cin, (int)cout);                                              \
-        return;                                                                                                                                \
-    }
-    CATTUS_WINO_DIAG_LAUNCH(1)
-    CATTUS_WINO_DIAG_LAUNCH(2)
-    CATTUS_WINO_DIAG_LAUNCH(3)
-    CATTUS_WINO_DIAG_LAUNCH(4)
-#undef CATTUS_WINO_DIAG_LAUNCH
     if (res)
         hipExtLaunchKernelGGL((conv3x3_wino_kernel<true>), grid, dim3(256), WN_LDS_TOTAL, st, ev_start, ev_stop, 0, in, (const H*)wu, bias, res, out,
                               sat, (int)cin, (int)cout);
@@ -351,9 +326,6 @@ void launch_conv3x3_wino(const float* in, const void* wu, const float* bias, con
 }
 
 hipError_t prepare_wino() {
-    for (const void* fn : {reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, 1>), reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, 2>),
-                           reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, 3>), reinterpret_cast<const void*>(&conv3x3_wino_kernel<true, 4>)})
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_TOTAL);
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_TOTAL);
     const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_TOTAL);
     return err != hipSuccess ? err : e2;

@@ -536,6 +536,8 @@ def write_summary(path, summary: dict):
             "node_evals": summary["node_evals"],
             "evals_per_sec": summary["node_evals"] / max(summary["seconds"], 1e-9),
             "games_seconds": summary["seconds"],
+            # f16 towers: activation values clamped at the f16 range (0 for every network inside it; include/cattus_hip.h)
+            "model.saturated": summary.get("saturated", 0),
         },
     }
     with open(path, "x") as f:  # create_new, as the reference
@@ -576,6 +578,13 @@ def main(argv=None):
     ev2 = None if same else load(args.model2_path)
     res = run_self_play(args.game, cfg, Net.hip(ev1), None if same else Net.hip(ev2), args.games_num, args.out_dir1,
                         args.out_dir2, keep_records=False)
+    # the f16 towers clamp what leaves the f16 range (cattus_stats.saturated): say so once, and put it in the summary
+    res["saturated"] = sum(int(ev.stats().get("saturated", 0)) for ev in (ev1, ev2) if ev is not None)
+    if res["saturated"]:
+        import sys
+
+        print(f"{Path(sys.argv[0]).name}: WARNING: {res['saturated']} activation values left the f16 range and were clamped: the "
+              f"outputs of dtype {inf.get('dtype', 'f16x2')!r} are not this network's -- use \"dtype\": \"f32\" in model.inference", file=sys.stderr)
     if args.summary_file:
         write_summary(args.summary_file, res)
 

@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const char* __restrict__ u
     const uint32_t voff = lane * 16;
     u32x4 ring[D][2];
     u32x4 l0, l1;
+    half8 puh[2] = {}, pvl[2] = {}, pvh[2] = {};  // MODE 2: operands of the two previous stages
 #define LOAD_STAGE(slot, ptr)                                                                                   \
     do {                                                                                                        \
         asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"             \
@@ -73,6 +74,15 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const char* __restrict__ u
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh, acc[f], 0, 0, 0);
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vl, acc[f], 0, 0, 0);
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vh, acc[f], 0, 0, 0);
+                } else if (MODE == 2) {
+                    // the three terms of a stage spread over three stages: consecutive MFMAs belong to different accumulators
+                    // (per accumulator the order of its terms is unchanged)
+                    const half8 uh = __builtin_bit_cast(half8, r0), ul = __builtin_bit_cast(half8, r1);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh, acc[f], 0, 0, 0);
+                    acc[(f + 15) & 15] = __builtin_amdgcn_mfma_f32_32x32x16_f16(puh[0], pvl[0], acc[(f + 15) & 15], 0, 0, 0);
+                    acc[(f + 14) & 15] = __builtin_amdgcn_mfma_f32_32x32x16_f16(puh[1], pvh[1], acc[(f + 14) & 15], 0, 0, 0);
+                    puh[1] = puh[0], pvh[1] = pvh[0];
+                    puh[0] = uh, pvl[0] = vl, pvh[0] = vh;
                 } else {  // consume the operands with four VALU instructions, no matrix pipe
                     acc[f][0] += __builtin_bit_cast(float, r0[0]) + __builtin_bit_cast(float, r1[0]) + (float)vh[0] + (float)vl[0];
                 }
@@ -248,6 +258,8 @@ int main(int argc, char** argv) {
     run(wino_kernel<16, 0, false>, "winograd, waves share V (4 cout blocks), ring 16", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<8, 0, true>, "winograd, waves 2 tile blocks x 2 cout blocks, ring 8", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<16, 0, true>, "winograd, waves 2 tile blocks x 2 cout blocks, ring 16", dU, grid, layers, dOut, lds, wf);
+    run(wino_kernel<8, 2, false>, "winograd, share V, ring 8, terms pipelined over 3 stages", dU, grid, layers, dOut, lds, wf);
+    run(wino_kernel<8, 2, true>, "winograd, 2 x 2, ring 8, terms pipelined over 3 stages", dU, grid, layers, dOut, lds, wf);
     run(wino8_kernel<8>, "winograd, 8 waves (2 per SIMD, 8 frequencies each), share V, ring 8", dU, grid, layers, dOut, lds, wf, 512);
     run(wino_kernel<16, 1, false>, "winograd operand streams alone (no MFMA), share V, ring 16", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<16, 1, true>, "winograd operand streams alone (no MFMA), 2 x 2, ring 16", dU, grid, layers, dOut, lds, wf);

@@ -28,7 +28,7 @@ def test_bench_prints_one_json_line_on_stdout():
     assert "workload" in out["config"] and "model" not in out["config"]
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["kernel"] == "conv3x3_splitw_kernel"
+    assert r["kernel"] == "conv3x3_wino_kernel"  # batch 256 on 8x8 boards: the split tower in Winograd form
     c = out["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert abs(out["value"] - 256 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6

@@ -8,6 +8,8 @@ Bars (DESIGN.md "Parity"):
     reference network's outputs on every fixture, and as close to the float64 run of the reference network as an
     f32 runtime is (bounds F16X2_* below).
   * dtype bf16: bf16 operands / f32 accumulation; per-fixture bounds in BF16_MEASURED below (2x the measured error).
+  * dtype f16: single-term f16 operands; per-fixture bounds in F16_MEASURED (2x the measured error, a tenth of bf16's).
+  * dtype f16x2 in Winograd form (evaluators of 8x8-board networks with max_batch >= 192): the f16x2 bars.
   * per-leaf results never depend on batch size, slot or neighbours (all dtypes, bit-exact).
 """
 
@@ -36,6 +38,12 @@ BF16_MEASURED = {
     "ttt_1x1": (2.3e-4, 1e-6), "ttt_2x64": (1.9e-3, 7.6e-4), "ttt_5x8": (2.7e-3, 7.4e-4),
 }
 BF16_FULL = {"20x256": (1.7e-2, 4.3e-3), "40x384": (5.2e-2, 1.2e-2)}
+# single-term f16 tower, the same way (round 4, profiles/r04_split_check.json): a tenth of bf16's error
+F16_MEASURED = {
+    "chess_1x1": (3.2e-5, 1e-6), "chess_20x256": (7.5e-4, 7.6e-5), "chess_2x64": (2.1e-4, 4.0e-5), "chess_7x16": (3.7e-4, 3.0e-5),
+    "hex11_1x1": (2.3e-5, 1e-6), "hex11_2x8": (7.2e-5, 1.3e-5), "hex4_7x16": (2.3e-4, 5.0e-5), "hex7_6x64": (3.7e-4, 5.6e-5),
+    "ttt_1x1": (1e-6, 1e-6), "ttt_2x64": (1.4e-4, 8.4e-5), "ttt_5x8": (2.3e-4, 5.4e-5),
+}
 # split precision against the float64 run of the reference network: measured max |dlogit| 7.4e-7, |dvalue| 2.1e-7 (chess
 # 20x256; the bit-exact f32 tower: 7.7e-7 / 1.9e-7, the reference's own f32 run: 3.3e-7 / 4.9e-8)
 F16X2_POLICY_ATOL_VS_F64, F16X2_VALUE_ATOL_VS_F64 = 1.5e-6, 5e-7
@@ -93,6 +101,24 @@ def test_bf16_within_stated_tolerance(name):
     dp, dv = BF16_MEASURED[name]
     assert np.abs(got_p - ref_p).max() <= 2 * dp, np.abs(got_p - ref_p).max()
     assert np.abs(got_v - ref_v).max() <= 2 * dv, np.abs(got_v - ref_v).max()
+
+
+@pytest.mark.parametrize("name", MFMA_SHAPES)
+def test_f16_within_stated_tolerance(name):
+    """The single-term f16 tower (dtype f16: f16 operands with per-channel pre-scaled weights, f32 accumulation, f32 heads) against the
+    reference network's outputs: twice the measured error per fixture, which is a tenth of the bf16 tower's."""
+    d, blob, z = blob_for(name)
+    planes = z["planes"]
+    with HipEvaluator(blob, batch_size=len(planes), plane_words=_plane_words(planes), dtype="f16") as ev:
+        got_p, got_v = ev.eval(planes)
+        again_p, again_v = ev.eval(planes[:1])
+        assert ev.stats()["saturated"] == 0
+    assert (again_p[0] == got_p[0]).all() and again_v[0] == got_v[0]  # a leaf's bits do not depend on the batch
+    dp, dv = F16_MEASURED[name]
+    assert np.abs(got_p - z["policy"]).max() <= 2 * dp, np.abs(got_p - z["policy"]).max()
+    assert np.abs(got_v - z["value"]).max() <= 2 * dv, np.abs(got_v - z["value"]).max()
+    bdp, bdv = BF16_MEASURED[name]
+    assert dp <= bdp and dv <= bdv  # never worse than bf16
 
 
 @pytest.mark.parametrize("name", golden_names())
