@@ -308,7 +308,7 @@ def search_threads(sp, world: int) -> int:
     return max(1, share - 4)
 
 
-def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, max_game_plies, keep_records, pool, torch, dev):
+def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, max_game_plies, keep_records, pool, torch, dev, batch=256):
     """Real self-play on this rank's shard of the games: C++ search + evaluation cache + this GPU's evaluator
     through cattus_hip_eval (host buffers, PCIe included), the reference's self-play settings.  With `pool`
     the records of all ranks are pooled on rank 0 by cattus_amd.dist.pool_records (gather) and the counters
@@ -320,9 +320,10 @@ def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, ma
     # search threads: the CPU share of this rank minus room for the two evaluation threads, the HIP runtime's
     # threads and the main thread (15 search threads on a 16-CPU share starved them: 261 k vs 337 k node-evals/s)
     threads = search_threads(sp, world)
-    # model.batch_size as a user would configure it: 256, or the number of concurrent games where that is smaller (one leaf per tree
-    # in flight: a batch can never hold more; the evaluator then also picks the kernels made for small batches)
-    bsz = min(256, slots)
+    # model.batch_size as a user would configure it for this many concurrent games (one leaf per tree in flight: a batch can never
+    # hold more than there are games, and with two batches in flight it holds well under half of them); the evaluator picks its
+    # kernels by it (the Winograd form of the f16x2 tower from 192 up, the small tiles of the direct kernels below)
+    bsz = min(batch, slots)
     with HipEvaluator(blob, batch_size=bsz, plane_words=1, dtype=dtype, device=local_rank) as ev:
         cfg = sp.make_config(sim_num=sims, batch_size=bsz, threads=threads, concurrent_games=slots, cache_size=1000000,
                              first_game=rank, game_stride=world, seed=1, max_game_plies=max_game_plies,
@@ -878,10 +879,13 @@ def main():
         # whole games, reduced simulation count: a measured games/hour
         full_sims = 64
         full_games = int(min(1024, max(64, 25.0 * capacity / (190.0 * full_sims)))) // 2 * 2
+        # batch_size 128: ~300 sequential searches fill ~120 slots per batch (measured: batch_fill), so a 256-leaf evaluator would run
+        # half empty all the way -- and in the f16x2 tower's Winograd form, which is built for full batches
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=full_games, slots=full_games, sims=full_sims, max_game_plies=0,
-                           keep_records=False, pool=False, torch=torch, dev=cdev)
+                           keep_records=False, pool=False, torch=torch, dev=cdev, batch=128)
         sp_full = reduce_leg(leg, torch, cdev, world)
-        sp_full.update(games_per_hour=sp_full["games"] * 3600.0 / sp_full["seconds"], settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype)
+        sp_full.update(games_per_hour=sp_full["games"] * 3600.0 / sp_full["seconds"], settings=SELFPLAY_SETTINGS_TEXT.replace("batch 256", "batch 128"),
+                       dtype=args.dtype)
         sp_out["games_per_hour_estimate"] = sp_out["plies_per_sec"] * 3600.0 / max(1.0, sp_full["plies_per_game"])
         out["selfplay_full_games"] = sp_full
         # BASELINE config 4's shape: 64 concurrent games per GPU (sequential search: at most 64 leaves per batch), records
@@ -890,7 +894,8 @@ def main():
         leg = selfplay_leg(blob, args.dtype, local_rank, rank, world, games=64, slots=64, sims=args.selfplay_sims, max_game_plies=6,
                            keep_records=True, pool=pool, torch=torch, dev=cdev)
         sp_c4 = reduce_leg(leg, torch, cdev, world)
-        sp_c4.update(max_game_plies=6, pool_seconds=leg["pool_seconds"], pooled=leg["pooled"], settings=SELFPLAY_SETTINGS_TEXT, dtype=args.dtype,
+        sp_c4.update(max_game_plies=6, pool_seconds=leg["pool_seconds"], pooled=leg["pooled"], settings=SELFPLAY_SETTINGS_TEXT.replace("batch 256", "batch 64"),
+                     dtype=args.dtype,
                      note="64 games per GPU, records gathered on rank 0 and counters all-reduced through torch.distributed 'nccl' (= RCCL) inside "
                           "the timed region; one leaf per tree in flight, so a batch holds at most 64 leaves"
                           + ("" if pool else "; NO process group came up on this box (see process_group): nothing was pooled"))

@@ -41,7 +41,7 @@ json.dump(b, open(prof / f"{R}_bench.json", "w"), indent=1)
 out = {"f16x2": {}, "bf16": {}}
 out["source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES (its own pass) and rocprofv3 --kernel-trace --stats of python3 bench.py --dtype D "
                  f"--steps 50 --warmup 5 (scripts/collect_profiles.sh {tag.name}), one MI355X box, round 4")
-for dt, kern in (("f16x2", "conv3x3_splitw_kernel"), ("bf16", "conv3x3_mfma_v2_kernel")):
+for dt, kern in (("f16x2", "conv3x3_wino_kernel"), ("bf16", "conv3x3_mfma_v2_kernel")):
     pm = json.load(open(prof / f"{R}_pmc_summary_{dt}.json"))
     # the 256 -> 256 layers: the STEM variants (third template flag) are left out
     busy = [(v["SQ_VALU_MFMA_BUSY_CYCLES"]["avg_per_launch"], v["SQ_VALU_MFMA_BUSY_CYCLES"]["launches"])

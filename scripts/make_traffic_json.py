@@ -41,7 +41,10 @@ def base_name(k: str) -> str:
     return k.replace("void ", "").replace("cattus::", "").split("<")[0].split("(")[0].strip()
 
 
-TOWER = {"f16x2": "conv3x3_splitw_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
+TOWER = {"f16x2": "conv3x3_wino_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
+# the f16x2 tower at batch 256 runs its 40 layers behind the stem in Winograd form: f32 rows in and out (+ the skip rows in 20 of them),
+# the layer's transformed weights U (16 frequencies x 256 x 256 pairs = 4.19 MB) once
+ALG["f16x2"] = (20 * (2 * ACT * 4 + 16 * 256 * 256 * 4) + 20 * (3 * ACT * 4 + 16 * 256 * 256 * 4)) / 40
 for dtype in ("f16x2", "bf16", "f16", "f32"):
     f = tag / f"pmc_summary_{dtype}.json"
     if not f.exists():
@@ -63,8 +66,8 @@ for dtype in ("f16x2", "bf16", "f16", "f32"):
             entry[name]["by_variant"] = variants
         if name == TOWER[dtype]:
             entry[name]["algorithmic_bytes_per_launch"] = int(ALG[dtype])
-            entry[name]["note"] = ("average over the 41 launches of a step (stem, 20 convs without and 20 with the skip rows); the excess over the "
-                                   "algorithmic bytes is the layer's weight set fetched once per XCD L2 (8 of them) instead of once")
+            entry[name]["note"] = ("average over the launches of a step (20 convs without and 20 with the skip rows; bf16 / f16 / f32: the stem too); the excess "
+                                   "over the algorithmic bytes is the layer's weight set fetched once per XCD L2 (8 of them) instead of once")
     out["by_dtype"][dtype] = entry
     if "planes_to_tensor_nchw64_kernel" in entry:
         out["by_dtype"].setdefault("any", {})["planes_to_tensor_nchw64_kernel"] = dict(entry["planes_to_tensor_nchw64_kernel"], algorithmic_bytes_per_launch=262144 * 4752)
