@@ -32,17 +32,37 @@
 
 namespace cattus {
 
+// Timing experiments only (scripts/build_variant.sh; the results are wrong with any of them set): WN_X_V4 reads the V fragments once
+// per four stages (what a wave owning 4 frequencies x 4 cout blocks would read), WN_X_NOTRANSFORM drops the transform slices from the
+// loop, WN_X_NOSTORE the output stores.
+#ifndef WN_X_V4
+#define WN_X_V4 0
+#endif
+#ifndef WN_X_NOTRANSFORM
+#define WN_X_NOTRANSFORM 0
+#endif
+#ifndef WN_X_PLAINSTORE
+#define WN_X_PLAINSTORE 0
+#endif
+#ifndef WN_X_NOSTORE
+#define WN_X_NOSTORE 0
+#endif
+
 constexpr int WN_D = 8;                    // U stages in flight per wave (16 registers... 8 stages x 2 fragments x 4 VGPRs = 64)
 constexpr int WN_VP = 80;                  // V image row: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad (b128 reads down 16 rows conflict-free)
 constexpr int WN_VF = 32 * WN_VP;          // one frequency: 32 tiles
 constexpr int WN_VIMG = 16 * WN_VF;        // one k-step's V: 40,960 B
 constexpr int WN_DROWS = 128;              // pixel rows of a workgroup: 2 boards x 64 slots
-constexpr int WN_DZERO = WN_DROWS * SP;    // behind the rows: a zero AREA of 28 rows -- a patch pixel off the board is read at
-constexpr int WN_DBUF = WN_DZERO + 28 * SP;  // zero area + the pixel's offset inside the patch ((3 * 8 + 3) rows at most): 22,464 B
+constexpr int WN_RP = 8 * SP + 64;         // pitch of a board row (8 pixel rows of 144 B) in the chunk image: 64 B of padding put the two tile
+                                           // rows of a read group on opposite halves of the 256-B bank row (see the transform's item)
+constexpr int WN_DZERO = 16 * WN_RP;       // behind the 16 board rows: a zero AREA -- a patch pixel off the board is read at zero area +
+constexpr int WN_ZAREA = 4608;             // (its own address mod 256: the same banks) + the pixel's offset inside the patch (<= 3 WN_RP + 3 SP + 64)
+constexpr int WN_DBUF = WN_DZERO + WN_ZAREA;  // 24,064 B
+static_assert(WN_DZERO % 256 == 0 && WN_DBUF % 256 == 0 && (2 * WN_VIMG) % 256 == 0, "the zero area keeps a read's banks only if it is 256-B aligned");
 constexpr int WN_LDS_D = 2 * WN_VIMG;
-constexpr int WN_LDS_TOTAL = WN_LDS_D + 2 * WN_DBUF;  // 126,848 B
+constexpr int WN_LDS_TOTAL = WN_LDS_D + 2 * WN_DBUF;  // 130,048 B
 constexpr int WN_PA = 2;                   // stages of look-ahead on the V fragments
-constexpr int WN_P = 5;                    // LDS-DMA pieces per wave and chunk: 4 x 5 = 20 >= the image's 18 KiB pieces
+constexpr int WN_P = 5;                    // LDS-DMA pieces per wave and chunk: 4 x 5 = 20 >= the image's 19 KiB pieces
 
 // LDS-DMA of 64 x 16 bytes, hidden from the compiler (it would otherwise order this wave's later LDS reads behind a vmcnt(0) of
 // its own, which also waits for the whole register ring): M0 = the wave-uniform LDS byte address, each lane its own source.
@@ -97,14 +117,15 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
     for (int d = 0; d < D; d++) load_stage(ring[d], wblk + (size_t)d * SW_STAGE);
 
-    // ---- LDS-DMA of an activation chunk: the padded image of conv3x3_splitw_kernel (row pitch 144, slot 8 re-reads slot 7) ----
+    // ---- LDS-DMA of an activation chunk: pixel rows of 144 B (eight 16-byte pieces of data, the ninth re-reads the eighth), 76
+    // pieces per board row (8 pixels + 4 pieces of padding that re-read too): 1,216 pieces = 19 instructions of 64 ----
     const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
     uint32_t off_a[WN_P], dst_a[WN_P];
 #pragma unroll
     for (int i = 0; i < WN_P; i++) {
-        const int id = min(wave * WN_P + i, 17);
-        const int sidx = id * 64 + lane, irow = sidx / 9, c = min(sidx - irow * 9, 7);
-        off_a[i] = (uint32_t)irow * row_bytes + c * 16;
+        const int id = min(wave * WN_P + i, 18);
+        const int sidx = id * 64 + lane, brow = sidx / 76, w = sidx - brow * 76, x = min(w / 9, 7), c = min(w - (w / 9) * 9, 7);
+        off_a[i] = (uint32_t)(brow * 8 + x) * row_bytes + c * 16;
         dst_a[i] = id * 1024;
     }
     auto issue_chunk = [&](int ch, int buf) __attribute__((always_inline)) {  // chunk ch -> buffer buf
@@ -113,53 +134,61 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
         for (int i = 0; i < WN_P; i++) glds16_asm(src + off_a[i], dst + dst_a[i]);
     };
-    for (int i = tid; i < 2 * 28 * 9; i += 256)  // the two zero areas: 28 rows of nine 16-byte slots each
-        reinterpret_cast<f32x4*>(smem + WN_LDS_D + (i / 252) * WN_DBUF + WN_DZERO)[i % 252] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 2 * (WN_ZAREA / 16); i += 256)  // the two zero areas
+        reinterpret_cast<f32x4*>(smem + WN_LDS_D + (i / (WN_ZAREA / 16)) * WN_DBUF + WN_DZERO)[i % (WN_ZAREA / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
     issue_chunk(0, 0);
     issue_chunk(1, 1);  // cin >= 64: at least two chunks
 
-    // ---- the transform's item: tile tid & 31 (board t >> 4, tile row (t >> 2) & 3, tile column t & 3), channel pair tid >> 5 ----
-    const int tt = tid & 31, chp = tid >> 5;
-    // The patch pixel (i, j) of the tile is image row base + 8 i + j; rows 0 / 3 and columns 0 / 3 of the patch can lie off the board
-    // (first / last tile row or column): those reads go to the zero area at the same offset.  One base register and four flags
-    // instead of sixteen row addresses.
-    const int tbase = (((tt >> 4) * 64 + (2 * ((tt >> 2) & 3) - 1) * 8 + 2 * (tt & 3) - 1) * SP) + chp * 8;
+    // ---- the transform's item: tile tt (board tt >> 4, tile row (tt >> 2) & 3, tile column tt & 3), channel pair chp of the k-step's 8 ----
+    // A 32-lane half of a wave -- the unit the LDS serves a ds_read_b64 / ds_write_b32 in -- is 8 consecutive tiles (two tile rows)
+    // x 4 consecutive channel pairs, and that makes both of the transform's accesses free of bank conflicts (SQ_LDS_BANK_CONFLICT: 61 %
+    // of the kernel's LDS cycles with 32 tiles x 1 pair per half):
+    //   V writes (bank = dword mod 32): dword 20 tt + chp -- 20 tt mod 32 runs through the 8 multiples of 4, chp fills the 4 between
+    //   patch reads (bank = dword mod 64, 2 dwords per lane): dword 36 (2 tx) + 304 (2 ty) + 2 chp + const -- 8 tx + 32 (ty & 1) + (0..7):
+    //   the 64 B of padding per board row (304 = 8 x 36 + 16) are what separates the two tile rows
+    const int tt = ((tid >> 5) & 3) * 8 + (tid & 7), chp = ((tid >> 7) << 2) + ((tid >> 3) & 3);
+    // The patch pixel (i, j) of the tile is at base + i WN_RP + j SP; rows 0 / 3 and columns 0 / 3 of the patch can lie off the board
+    // (first / last tile row or column): those reads go to the zero area, at the read's own address mod 256 (the same banks) + the
+    // same offset.  One base register and four masks instead of sixteen addresses.
+    const int tbase = ((tt >> 4) * 8 + 2 * ((tt >> 2) & 3) - 1) * WN_RP + (2 * (tt & 3) - 1) * SP + chp * 8;
     const int zbase = WN_DZERO + chp * 8;
     const int tdelta = tbase - zbase;  // address = zero area + (tdelta & mask): the masks are all ones where the patch row / column is on the board
-    const int mr0 = ((tt >> 2) & 3) != 0 ? -1 : 0, mr3 = ((tt >> 2) & 3) != 3 ? -1 : 0, mc0 = (tt & 3) != 0 ? -1 : 0, mc3 = (tt & 3) != 3 ? -1 : 0;
+    const int mr0 = ((tt >> 2) & 3) != 0 ? -1 : 255, mr3 = ((tt >> 2) & 3) != 3 ? -1 : 255, mc0 = (tt & 3) != 0 ? -1 : 255, mc3 = (tt & 3) != 3 ? -1 : 255;
     const int vwr = tt * WN_VP + chp * 4;  // where this item's hi pair goes inside a frequency's block (the lo pair 32 further)
     f32x2 dd[16];                          // the patch as f32, then (in place) B^T d, then B^T d B
     float vmax = 0.0f;                     // largest |V| this thread has seen
     // kp: which half (16 channels) of the chunk; slices 0..3 read a patch row each, 4..7 do the row transform of a column,
-    // 8..11 the column transform of a row and write its four frequencies.  Everything else: nothing.
-    auto transform_slice = [&](int slice, int dbase, int kp, int vbase) __attribute__((always_inline)) {
+    // 8..15 the column transform of half a row each: two frequencies split into (hi, lo) and written.
+    // A slice comes in two parts, issued behind the first and the second MFMA of its stage: the wave issues in order and the three
+    // MFMAs of a stage wait for each other (one accumulator), so VALU work has to sit BETWEEN them to run in their shadow -- left
+    // behind the third it overlapped with that one only, and the transform cost the loop 5 of its 34 us.
+    auto transform_slice = [&](int slice, int part, int dbase, int kp, int vbase) __attribute__((always_inline)) {
         if (slice < 4) {
+            if (part != 0) return;
             const int i = slice;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int mask = (i == 0 ? mr0 : i == 3 ? mr3 : -1) & (j == 0 ? mc0 : j == 3 ? mc3 : -1);
-                dd[i * 4 + j] = *reinterpret_cast<const f32x2*>(smem + dbase + zbase + (tdelta & mask) + ((i * 8 + j) * SP + kp * 64));
+                dd[i * 4 + j] = *reinterpret_cast<const f32x2*>(smem + dbase + zbase + (tdelta & mask) + (i * WN_RP + j * SP + kp * 64));
             }
         } else if (slice < 8) {
+            if (part != 1) return;
             const int j = slice - 4;  // column j: B^T over the rows
             const f32x2 d0 = dd[j], d1 = dd[4 + j], d2 = dd[8 + j], d3 = dd[12 + j];
             dd[j] = d0 - d2, dd[4 + j] = d1 + d2, dd[8 + j] = d2 - d1, dd[12 + j] = d1 - d3;
-        } else if (slice < 12) {
-            const int i = slice - 8;  // row i: B over the columns, then split and store the frequencies 4 i .. 4 i + 3
+        } else {
+            // slices 8..15: row (slice - 8) / 2, B over the columns, frequency 2 ((slice - 8) & 1) + part of that row
+            const int i = (slice - 8) >> 1, l = ((slice - 8) & 1) * 2 + part;
             const f32x2 t0 = dd[i * 4], t1 = dd[i * 4 + 1], t2 = dd[i * 4 + 2], t3 = dd[i * 4 + 3];
-            const f32x2 v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
-#pragma unroll
-            for (int l = 0; l < 4; l++) {
-                f32x2 x = v[l];
-                // the f16 range is left HERE in this tower (activations are f32): saturate rather than overflow, and count it
-                vmax = fmaxf(fmaxf(vmax, fabsf(x[0])), fabsf(x[1]));  // one v_max3: checked once, at the end
-                x = __builtin_elementwise_min(__builtin_elementwise_max(x, f32x2{-65504.0f, -65504.0f}), f32x2{65504.0f, 65504.0f});
-                const f16x2v hi = __builtin_convertvector(x, f16x2v);
-                const f16x2v lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), f16x2v);
-                char* q = smem + vbase + (i * 4 + l) * WN_VF + vwr;
-                *reinterpret_cast<f16x2v*>(q) = hi;
-                *reinterpret_cast<f16x2v*>(q + 32) = lo;
-            }
+            f32x2 x = l == 0 ? t0 - t2 : l == 1 ? t1 + t2 : l == 2 ? t2 - t1 : t1 - t3;
+            // the f16 range is left HERE in this tower (activations are f32): saturate rather than overflow, and count it
+            vmax = fmaxf(fmaxf(vmax, fabsf(x[0])), fabsf(x[1]));  // one v_max3: checked once, at the end
+            x = __builtin_elementwise_min(__builtin_elementwise_max(x, f32x2{-65504.0f, -65504.0f}), f32x2{65504.0f, 65504.0f});
+            const f16x2v hi = __builtin_convertvector(x, f16x2v);
+            const f16x2v lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), f16x2v);
+            char* q = smem + vbase + (i * 4 + l) * WN_VF + vwr;
+            *reinterpret_cast<f16x2v*>(q) = hi;
+            *reinterpret_cast<f16x2v*>(q + 32) = lo;
         }
     };
 
@@ -172,7 +201,10 @@ __global__ void __launch_bounds__(256, 1)
     // ---- prologue: both chunks and the ring's first stages have landed; V of k-step 0 ----
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-    for (int s = 0; s < 12; s++) transform_slice(s, WN_LDS_D, 0, 0);
+    for (int s = 0; s < 16; s++) {
+        transform_slice(s, 0, WN_LDS_D, 0, 0);
+        transform_slice(s, 1, WN_LDS_D, 0, 0);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     const int vrd = r * WN_VP + h * 16;  // this lane's fragment inside a frequency's block: tile r, channels 8 h .. 8 h + 7 (lo 32 further)
@@ -186,6 +218,7 @@ __global__ void __launch_bounds__(256, 1)
         frag vh[PR], vl[PR];
 #pragma unroll
         for (int q = 0; q < PA; q++) {
+            if (WN_X_V4 && q > 0) { vh[q] = vh[0], vl[q] = vl[0]; continue; }
             vh[q] = *reinterpret_cast<const frag*>(smem + vimg + q * WN_VF + vrd);
             vl[q] = *reinterpret_cast<const frag*>(smem + vimg + q * WN_VF + vrd + 32);
         }
@@ -193,8 +226,12 @@ __global__ void __launch_bounds__(256, 1)
         for (int f = 0; f < 16; f++) {
             const int cur = f % PR, nxt = (f + PA) % PR;
             if (f + PA < 16) {
-                vh[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd);
-                vl[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd + 32);
+                if (!WN_X_V4 || ((f + PA) & 3) == 0) {
+                    vh[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd);
+                    vl[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd + 32);
+                } else {
+                    vh[nxt] = vh[(f + PA - 1) % PR], vl[nxt] = vl[(f + PA - 1) % PR];
+                }
             }
             // all but the youngest 2 (D - 1) ring loads have returned -- plus, for the D stages whose own loads went out before this
             // body's LDS-DMA (issued between its stages 15 and 16), those WN_P younger DMA instructions
@@ -208,13 +245,18 @@ __global__ void __launch_bounds__(256, 1)
             const frag uh = __builtin_bit_cast(frag, ring[f % D][0]);
             const frag ul = __builtin_bit_cast(frag, ring[f % D][1]);
             Mfma<T>::mac(ul, vh[cur], acc[f]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!WN_X_NOTRANSFORM) transform_slice(f, 0, dbase, kp, vnext);
+            __builtin_amdgcn_sched_barrier(0);
             Mfma<T>::mac(uh, vl[cur], acc[f]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!WN_X_NOTRANSFORM) transform_slice(f, 1, dbase, kp, vnext);
+            __builtin_amdgcn_sched_barrier(0);
             Mfma<T>::mac(uh, vh[cur], acc[f]);
             {  // refill D stages ahead; past the layer's end the last stage is re-read (the count of loads in flight stays fixed)
                 const int sn = min(s0 + f + D, nst - 1);
                 load_stage(ring[f % D], wblk + (size_t)sn * SW_STAGE);
             }
-            transform_slice(f, dbase, kp, vnext);
         }
     };
     for (int c = 0; c < nch; c++) {
@@ -248,6 +290,20 @@ __global__ void __launch_bounds__(256, 1)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the V images
     char* stage = smem + wave * 16384;
     const int board = er >> 4, ty = (er >> 2) & 3, tx = er & 3;
+    // Final layout: lane = (pixel k * 8 + (lane >> 3), couts 4 pc .. 4 pc + 3 with pc = lane & 7): eight lanes cover a pixel's 128 bytes
+    // (this wave's 32 couts), so every skip load and every store instruction moves whole 128-byte lines.  (As (pixel, 8 couts) per lane
+    // and two 16-byte stores each, a store instruction wrote 16 bytes out of every 32: half-written lines cost 1.5 us per launch.)
+    const int pc = elane & 7;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(bias + cout0 + pc * 4);
+    const f32x4 ds4 = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + pc * 4);
+    // the skip rows: requested AHEAD of the output transform (the ring's 64 registers are free from the drain on), used behind the
+    // transpose: their latency hides behind the transform's ~800 VALU instructions
+    f32x4 skip[16];
+    if (HAS_RES) {
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            skip[k] = *reinterpret_cast<const f32x4*>(res + ((size_t)row0 + k * 8 + (elane >> 3)) * (size_t)cout + cout0 + pc * 4);
+    }
     // four accumulator elements (couts 8 g + 4 h ..) of every frequency at a time, each read out of its AGPR by an asm statement:
     // left to itself the compiler copies all sixteen 16-register accumulators into VGPRs at once and spills
 #pragma unroll
@@ -271,40 +327,26 @@ __global__ void __launch_bounds__(256, 1)
             *reinterpret_cast<f32x4*>(stage + px * 128 + (((g * 2 + eh) ^ (px & 7)) << 4)) = yv;
         }
     }
-    // the skip rows of the lane's eight (pixel, 8 couts) pieces of the final layout: requested behind the output transform (whose temporaries leave no room for these 64 registers), used behind the transpose
-    f32x4 skip[8][2];
-    if (HAS_RES) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const size_t at = ((size_t)row0 + k * 16 + (elane >> 2)) * (size_t)cout + cout0 + (elane & 3) * 8;
-            skip[k][0] = *reinterpret_cast<const f32x4*>(res + at);
-            skip[k][1] = *reinterpret_cast<const f32x4*>(res + at + 4);
-        }
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a wave reads back only what it wrote itself
-    const int cg = elane & 3;               // this lane's 8 couts: 8 cg .. 8 cg + 7 of the wave's 32
-    f32x4 bias8[2], ds8[2];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        bias8[q] = *reinterpret_cast<const f32x4*>(bias + cout0 + cg * 8 + q * 4);
-        ds8[q] = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + cg * 8 + q * 4);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int px = k * 16 + (elane >> 2);
-        const size_t at = ((size_t)row0 + px) * (size_t)cout + cout0 + cg * 8;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(stage + px * 128 + (((2 * cg) ^ (px & 7)) << 4));
-        const f32x4 b = *reinterpret_cast<const f32x4*>(stage + px * 128 + (((2 * cg + 1) ^ (px & 7)) << 4));
-        f32x4 v0, v1;
+    for (int k = 0; k < 16; k++) {
+        const int px = k * 8 + (elane >> 3);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(stage + px * 128 + ((pc ^ (px & 7)) << 4));
+        f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             // the inverse weight scale is a power of two: the product is exact, the fma rounds once
-            float x0 = __builtin_fmaf(a[j], ds8[0][j], bias8[0][j]), x1 = __builtin_fmaf(b[j], ds8[1][j], bias8[1][j]);
-            if (HAS_RES) x0 = x0 + skip[k][0][j], x1 = x1 + skip[k][1][j];
-            v0[j] = x0 > 0.0f ? x0 : 0.0f, v1[j] = x1 > 0.0f ? x1 : 0.0f;
+            float x = __builtin_fmaf(a[j], ds4[j], bias4[j]);
+            if (HAS_RES) x = x + skip[k][j];
+            v[j] = x > 0.0f ? x : 0.0f;
         }
-        __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(out + at));
-        __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(out + at) + 1);
+        if (WN_X_NOSTORE && v[0] != 12345.678f) continue;
+        f32x4* dst = reinterpret_cast<f32x4*>(out + ((size_t)row0 + px) * (size_t)cout + cout0 + pc * 4);
+        if (WN_X_PLAINSTORE) {
+            *dst = v;
+            continue;
+        }
+        __builtin_nontemporal_store(v, dst);
     }
     if (vmax > 65504.0f) atomicAdd(sat, 1u);  // a transformed input left the f16 range somewhere in this thread's share
 }

@@ -30,7 +30,9 @@ constexpr int STAGE_BYTES = 2048;               // U hi + lo fragment of one cou
 constexpr int V_BYTES = NF * 33 * 144;          // one 32-tile block's V image for one 32-channel chunk: [f][32 tiles + pad][144 B]
 
 // MODE 0: Winograd loop; 1: the same without MFMAs (operand delivery alone); SHARE_U: waves (tile block w >> 1, cout block w & 1)
-template <int D, int MODE, bool SHARE_U>
+// VMODE 0: V fragments per stage; 1: once per 4 stages (a wave owns 4 frequencies x 4 cout blocks: a quarter of the LDS reads, the
+// same U stream); 2: never (V in registers: the U stream alone under MFMAs).  UMODE 1: no U loads (the V reads alone under MFMAs).
+template <int D, int MODE, bool SHARE_U, int VMODE = 0, int UMODE = 0>
 __global__ void __launch_bounds__(256, 1) wino_kernel(const char* __restrict__ u, int layers, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -48,6 +50,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const char* __restrict__ u
     u32x4 ring[D][2];
     u32x4 l0, l1;
     half8 puh[2] = {}, pvl[2] = {}, pvh[2] = {};  // MODE 2: operands of the two previous stages
+    half8 vh = *reinterpret_cast<const half8*>(vrow), vl = *reinterpret_cast<const half8*>(vrow + 64);
 #define LOAD_STAGE(slot, ptr)                                                                                   \
     do {                                                                                                        \
         asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"             \
@@ -65,10 +68,13 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const char* __restrict__ u
             for (int f = 0; f < NF; f++) {
                 const int s = k * NF + f;
                 asm volatile("" ::: "memory");
-                const half8 vh = *reinterpret_cast<const half8*>(vrow + f * 33 * 144 + (k & 1) * 32);
-                const half8 vl = *reinterpret_cast<const half8*>(vrow + f * 33 * 144 + (k & 1) * 32 + 64);
+                if (VMODE == 0 || (VMODE == 1 && (f & 3) == 0)) {
+                    const int fv = VMODE == 1 ? wave * 4 + (f >> 2) : f;
+                    vh = *reinterpret_cast<const half8*>(vrow + fv * 33 * 144 + (k & 1) * 32);
+                    vl = *reinterpret_cast<const half8*>(vrow + fv * 33 * 144 + (k & 1) * 32 + 64);
+                }
                 u32x4 r0 = ring[f % D][0], r1 = ring[f % D][1];
-                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(2 * (D - 1)));
+                if (UMODE == 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(2 * (D - 1)));
                 if (MODE == 0) {
                     const half8 uh = __builtin_bit_cast(half8, r0), ul = __builtin_bit_cast(half8, r1);
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh, acc[f], 0, 0, 0);
@@ -87,7 +93,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const char* __restrict__ u
                     acc[f][0] += __builtin_bit_cast(float, r0[0]) + __builtin_bit_cast(float, r1[0]) + (float)vh[0] + (float)vl[0];
                 }
                 const int sn = s + D < STAGES ? s + D : STAGES - 1;
-                LOAD_STAGE(f % D, wp + (size_t)sn * STAGE_BYTES);
+                if (UMODE == 0) LOAD_STAGE(f % D, wp + (size_t)sn * STAGE_BYTES);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -260,6 +266,10 @@ int main(int argc, char** argv) {
     run(wino_kernel<16, 0, true>, "winograd, waves 2 tile blocks x 2 cout blocks, ring 16", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<8, 2, false>, "winograd, share V, ring 8, terms pipelined over 3 stages", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<8, 2, true>, "winograd, 2 x 2, ring 8, terms pipelined over 3 stages", dU, grid, layers, dOut, lds, wf);
+    run(wino_kernel<8, 0, false, 1>, "winograd, a wave = 4 frequencies x 4 cout blocks (V read once per 4 stages), ring 8", dU, grid, layers, dOut, lds, wf);
+    run(wino_kernel<8, 0, false, 2>, "winograd, U stream alone under the MFMAs (V in registers), ring 8", dU, grid, layers, dOut, lds, wf);
+    run(wino_kernel<8, 0, false, 0, 1>, "winograd, V reads alone under the MFMAs (U in registers)", dU, grid, layers, dOut, lds, wf);
+    run(wino_kernel<8, 0, false, 2, 1>, "winograd, MFMAs alone (U and V in registers)", dU, grid, layers, dOut, lds, wf);
     run(wino8_kernel<8>, "winograd, 8 waves (2 per SIMD, 8 frequencies each), share V, ring 8", dU, grid, layers, dOut, lds, wf, 512);
     run(wino_kernel<16, 1, false>, "winograd operand streams alone (no MFMA), share V, ring 16", dU, grid, layers, dOut, lds, wf);
     run(wino_kernel<16, 1, true>, "winograd operand streams alone (no MFMA), 2 x 2, ring 16", dU, grid, layers, dOut, lds, wf);
