@@ -361,7 +361,7 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
             std::vector<double> U((size_t)cout * cin * 16);
             std::vector<float> bwv((size_t)2 * cout_pad, 0.0f);
             memcpy(bwv.data(), f.b.data(), cout * sizeof(float));
-            std::vector<_Float16> wu((size_t)16 * cout_pad * cin_pad * 2, (_Float16)0.0f);
+            std::vector<_Float16> wu((size_t)16 * cout_pad * cin_pad * 2 + (size_t)WINO_RING_STAGES * 1024, (_Float16)0.0f);  // + the ring's overrun
             for (uint32_t co = 0; co < cout_pad; co++) {
                 double m = 0.0;
                 if (co < cout)

@@ -82,6 +82,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 // activations between its layers); wu = G g G^T as (hi, lo) f16 pairs pre-scaled per output channel, in fragment order
 // [cout / 32][(cin / 16) k-steps x 16 frequencies][hi | lo][lane][8 f16] (wino_frag_index); bias = [cout biases | cout inverse
 // scales] of THAT scaling; sat: counts threads whose transformed inputs left the f16 range.
+// the kernel's weight ring reads WINO_RING_STAGES stages (of 2,048 B) past a cout block's end: wu is allocated with that much behind it
+constexpr int WINO_RING_STAGES = 8;
 bool wino_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S);
 inline size_t wino_frag_index(uint32_t f, uint32_t co, uint32_t ci, uint32_t part, uint32_t cin_pad) {
     const uint32_t nst = cin_pad / 16 * 16, stage = (ci >> 4) * 16 + f, lane = ((ci >> 3) & 1) * 32 + (co & 31);

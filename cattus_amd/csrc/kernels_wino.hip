@@ -48,7 +48,7 @@ namespace cattus {
 #define WN_X_NOSTORE 0
 #endif
 
-constexpr int WN_D = 8;                    // U stages in flight per wave (16 registers... 8 stages x 2 fragments x 4 VGPRs = 64)
+constexpr int WN_D = WINO_RING_STAGES;     // U stages in flight per wave (8 stages x 2 fragments x 4 VGPRs = 64 registers)
 constexpr int WN_VP = 80;                  // V image row: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad (b128 reads down 16 rows conflict-free)
 constexpr int WN_VF = 32 * WN_VP;          // one frequency: 32 tiles
 constexpr int WN_VIMG = 16 * WN_VF;        // one k-step's V: 40,960 B
@@ -185,7 +185,14 @@ __global__ void __launch_bounds__(256, 1)
             vmax = fmaxf(fmaxf(vmax, fabsf(x[0])), fabsf(x[1]));  // one v_max3: checked once, at the end
             x = __builtin_elementwise_min(__builtin_elementwise_max(x, f32x2{-65504.0f, -65504.0f}), f32x2{65504.0f, 65504.0f});
             const f16x2v hi = __builtin_convertvector(x, f16x2v);
-            const f16x2v lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), f16x2v);
+            // lo = f16(x - hi): the difference is exact in f32 (hi is x rounded to 11 bits), so one mixed-precision fma per element
+            // (v_fma_mixlo/hi_f16: f16 operand in, f32 arithmetic, f16 out) gives the bits of convert - subtract - convert
+            // in asm: the compiler rewrites the fma back into convert - subtract - convert (5 instructions instead of 2).  The s_nop covers
+            // the partial-register write ahead of whatever reads lo next (the compiler does not see inside).
+            f16x2v lo;
+            asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
+                : "=&v"(lo)
+                : "v"(hi), "v"(x[0]), "v"(x[1]));
             char* q = smem + vbase + (i * 4 + l) * WN_VF + vwr;
             *reinterpret_cast<f16x2v*>(q) = hi;
             *reinterpret_cast<f16x2v*>(q + 32) = lo;
@@ -210,7 +217,7 @@ __global__ void __launch_bounds__(256, 1)
     const int vrd = r * WN_VP + h * 16;  // this lane's fragment inside a frequency's block: tile r, channels 8 h .. 8 h + 7 (lo 32 further)
     // One k-step: 16 stages on the V image at `vimg`, with the transform of the NEXT k-step (chunk image at `dbase`, half kp, into
     // the other V image) sliced in between.  JB: the stage's index inside the chunk body (0 or 16), which fixes the wait counts.
-    auto kstep = [&](int s0, int vimg, int dbase, int kp, int vnext, auto jb_tag) __attribute__((always_inline)) {
+    auto kstep = [&](const char* wchunk, int vimg, int dbase, int kp, int vnext, auto jb_tag) __attribute__((always_inline)) {
         constexpr int JB = decltype(jb_tag)::value;
         // WN_PA stages of look-ahead on the V fragments (never across the k-step: the next image is being written): an LDS read
         // queues behind the transform slices' reads and writes of this wave (the LDS queue is in order), so one stage is not enough
@@ -253,20 +260,22 @@ __global__ void __launch_bounds__(256, 1)
             if (!WN_X_NOTRANSFORM) transform_slice(f, 1, dbase, kp, vnext);
             __builtin_amdgcn_sched_barrier(0);
             Mfma<T>::mac(uh, vh[cur], acc[f]);
-            {  // refill D stages ahead; past the layer's end the last stage is re-read (the count of loads in flight stays fixed)
-                const int sn = min(s0 + f + D, nst - 1);
-                load_stage(ring[f % D], wblk + (size_t)sn * SW_STAGE);
-            }
+            // refill D stages ahead: chunk pointer + a constant (two scalar instructions; clamped to the layer's last stage it was a
+            // dependent chain of six per stage in a wave that issues in order).  Past the layer's end that reads the next cout block's
+            // first stages, or the WINO_RING_STAGES stages of padding behind the last block: nobody uses them, and the count of loads
+            // in flight stays fixed
+            load_stage(ring[f % D], wchunk + (size_t)(JB + f + D) * SW_STAGE);
         }
     };
     for (int c = 0; c < nch; c++) {
         const int dcur = WN_LDS_D + (c & 1) * WN_DBUF, dnext = WN_LDS_D + ((c + 1) & 1) * WN_DBUF;
+        const char* wchunk = wblk + (size_t)c * 32 * SW_STAGE;  // this chunk's 32 stages of U
         // k-step 2c on image 0; meanwhile V of k-step 2c + 1 (the chunk's second half) -> image 1
-        kstep(c * 32, 0, dcur, 1, WN_VIMG, std::integral_constant<int, 0>{});
+        kstep(wchunk, 0, dcur, 1, WN_VIMG, std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // image 1 is complete, image 0 and chunk c are free
         issue_chunk(min(c + 2, nch - 1), c & 1);                           // -> the buffer chunk c was in (past the end: a re-read nobody uses)
         // k-step 2c + 1 on image 1; meanwhile V of k-step 2c + 2 (the next chunk's first half) -> image 0
-        kstep(c * 32 + 16, WN_VIMG, dnext, 0, 0, std::integral_constant<int, 16>{});
+        kstep(wchunk, WN_VIMG, dnext, 0, 0, std::integral_constant<int, 16>{});
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // the ring's last refills (nobody reads them) and the last DMA.  The ring's registers are operands of the wait: to the compiler
