@@ -56,6 +56,13 @@ __host__ __device__ constexpr size_t frag_packed_index(uint32_t row, uint32_t k,
     return ((((size_t)(row >> 5) * (K / KSTEP) + k / KSTEP) * 2 + (k % KSTEP) / HALF) * 32 + (row & 31)) * HALF + k % HALF;
 }
 
+// Off-board taps of the 3x3 kernels read zeros.  One zero ROW behind an image's rows put every such lane of a ds_read_b128 group on
+// one bank slot, colliding with whichever lane's real row shares it (a quarter of the conv kernels' LDS cycles were bank conflicts).
+// A zero AREA instead, 256-B aligned and read at (the off-board row's own address mod 256), gives the lane the banks its row would
+// have had -- the group's addresses stay linear in the pixel index, as conflict-free as on a board without borders.  ZAREA_SP: for
+// images of 144-byte rows read as (hi at +0, lo at +64): 255 + 64 + 16 bytes rounded up; 128-byte swizzled rows need 256.
+constexpr int ZAREA_SP = 352;
+
 // The f16 towers store activations as f16 and clamp them at 65504 instead of letting them overflow to infinity.  A clamped
 // value is a wrong value: it is counted (atomic add on the clamp path only -- a network inside the f16 range never gets
 // here) into the evaluator's sticky counter, which cattus_hip_stats reports as `saturated`.

@@ -199,9 +199,10 @@ __device__ unsigned long long g_stamps[512 * 8 * 8];
 // LDS map: weight ring first so that (ring slot, tap) offsets fold into ds_read immediates.
 constexpr int V2_SLAB = 3 * 8192;
 constexpr int V2_LDS_W = 0;                           // 3 x 24 KiB
-constexpr int V2_LDS_ZERO = 3 * V2_SLAB;              // 128 B of zeros
-constexpr int V2_LDS_ACT = V2_LDS_ZERO + 128;         // 2 x 32 KiB
-constexpr int V2_LDS_TOTAL = V2_LDS_ACT + 2 * 32768;  // 139392 B
+constexpr int V2_LDS_ZERO = 3 * V2_SLAB;              // 256 B of zeros (a whole bank row: device_common.h, ZAREA_SP)
+constexpr int V2_LDS_ACT = V2_LDS_ZERO + 256;         // 2 x 32 KiB
+constexpr int V2_LDS_TOTAL = V2_LDS_ACT + 2 * 32768;  // 139520 B
+static_assert(V2_LDS_ZERO % 256 == 0 && V2_LDS_ACT % 256 == 0, "off-board reads keep their row's banks only if both are 256-B aligned");
 
 
 #ifndef CATTUS_NLOAD
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
     const int cout0 = (logical % ncb) * CPW;
     const int row0 = (logical / ncb) * RW;  // first tower row (board * slots + pixel slot) of this workgroup
 
-    if (tid < 8) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 16) reinterpret_cast<f32x4*>(smem + V2_LDS_ZERO)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero row is written before the first barrier
 
     const int nch = cin / KC;
@@ -480,8 +481,9 @@ __global__ void __launch_bounds__(256 + 64 * NLOAD, (4 + NLOAD) / 4)
                     const int hh = ph[pb] + (g - 1) + opaque, ww = pw[pb] + dxi - 1;
                     const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
                     const int q = hh * S + ww;
-                    const int rowa = ok ? abase + q * 128 : V2_LDS_ZERO;
-                    const int x0 = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
+                    // off the board: the zero area, at the row's own address mod 256 (q may be negative: only its low bits are used)
+                    const int rowa = ok ? abase + q * 128 : V2_LDS_ZERO + (q & 1) * 128;
+                    const int x0 = (h ^ ((q >> 1) & 7)) << 4;
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) baddr[dxi][pb][ks] = rowa + (x0 ^ (ks << 5));
                 }
@@ -662,10 +664,11 @@ extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps(un
 // flags & CONV_OUT_F32: the output is written as plain f32 [row][cout] (the last tower layer, for the f32 head kernels).
 constexpr int SP_TAP = 64 * SP;                         // the 64 cout rows of one tap
 constexpr int SP_SLAB = 3 * SP_TAP;                     // 27,648 B = 27 LDS-DMA pieces of 1 KiB
-constexpr int SP_ZERO = 256 * SP;                       // a buffer's zero row (off-board taps read it), behind its 256 rows
-constexpr int SP_ABUF = SP_ZERO + SP;                   // 37,008 B; the rows alone are 36 pieces
+constexpr int SP_ZERO = 256 * SP;                       // a buffer's zero area (off-board taps read it: device_common.h), behind its 256 rows
+constexpr int SP_ABUF = SP_ZERO + ZAREA_SP;             // 37,216 B; the rows alone are 36 pieces
 constexpr int SP_LDS_ACT = 3 * SP_SLAB;
-constexpr int SP_LDS_TOTAL = SP_LDS_ACT + 2 * SP_ABUF;  // 156,960 B
+constexpr int SP_LDS_TOTAL = SP_LDS_ACT + 2 * SP_ABUF;  // 157,376 B
+static_assert(SP_ZERO % 256 == 0, "off-board reads keep their row's banks only if the zero area is 256-B aligned inside the buffer");
 constexpr int SP_WPL = 7, SP_APL = 5;                   // pieces per loader wave: 28 >= 27 per slab, 20 >= 18 per half chunk
 
 template <bool HAS_RES, bool BIG, bool STEM, int CB>
@@ -693,7 +696,8 @@ __global__ void __launch_bounds__(512, 2)
     const int cout0 = (logical % ncb) * CPW;
     const int row0 = (logical / ncb) * ROWS_PER_WG;
 
-    if (tid < 18) reinterpret_cast<f32x4*>(smem + SP_LDS_ACT + (tid / 9) * SP_ABUF + SP_ZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 2 * (ZAREA_SP / 16))
+        reinterpret_cast<f32x4*>(smem + SP_LDS_ACT + (tid / (ZAREA_SP / 16)) * SP_ABUF + SP_ZERO)[tid % (ZAREA_SP / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero rows are written before the first barrier
 
     const int nch = cin / KC;
@@ -828,7 +832,8 @@ __global__ void __launch_bounds__(512, 2)
         for (int t9 = 0; t9 < 9; t9++) {
             const int hh = ph + t9 / 3 - 1, ww = pw + t9 % 3 - 1;
             const bool ok = pvalid && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
-            rowa[t9][pb] = (ok ? (board_row + hh * S + ww) * SP : SP_ZERO) + h * 16;
+            const int at = (board_row + hh * S + ww) * SP + h * 16;  // off the board: only its low 8 bits are used
+            rowa[t9][pb] = ok ? at : SP_ZERO + (at & 255);
         }
     }
     int aaddr[CB];
@@ -1019,7 +1024,7 @@ __global__ void __launch_bounds__(512, 2)
 // XCD's L2), and while even that grid would leave half of the CUs empty the workgroup covers 128 rows instead of 256
 // (PBW = 1: 32 pixels per consumer wave, half the MFMA chain per wave, twice the workgroups): 14.0 us per launch at 64
 // leaves of chess 20x256, 11.9 at 17 (256-row workgroups: 18.6 / 18.4; the LDS-ring kernel: 22.5 / 22.0).
-constexpr int sw_lds_total(int cb, int pbw = 2) { return 2 * (128 * pbw * SP + SP) + 128 * pbw * 32 * cb * 4; }  // 139,552 B at CB = 2
+constexpr int sw_lds_total(int cb, int pbw = 2) { return 2 * (128 * pbw * SP + ZAREA_SP) + 128 * pbw * 32 * cb * 4; }  // 139,968 B at CB = 2
 
 // PBW: 32-pixel blocks per consumer wave.  2: the workgroup covers 256 tower rows (64 pixels per wave); 1 (with CB = 1, for
 // grids that would otherwise leave CUs empty: <= 64 leaves of an 8x8 game at 256 filters): 128 rows, 32 pixels per wave -- twice
@@ -1037,8 +1042,9 @@ __global__ void __launch_bounds__(512, 2)
     static_assert(PBW == 2 || (PBW == 1 && CB == 1), "the 128-row workgroup exists for the 32-cout tile only");
     constexpr int RW = 128 * PBW;       // tower rows of this workgroup
     constexpr int PXW = 32 * PBW;       // pixels (rows) per consumer wave
-    constexpr int ZERO = RW * SP;       // a buffer's zero row, behind its RW rows
-    constexpr int ABUF = ZERO + SP;     // bytes of an activation buffer
+    constexpr int ZERO = RW * SP;       // a buffer's zero area (device_common.h), behind its RW rows
+    constexpr int ABUF = ZERO + ZAREA_SP;  // bytes of an activation buffer
+    static_assert(ZERO % 256 == 0, "off-board reads keep their row's banks only if the zero area is 256-B aligned inside the buffer");
     constexpr int SKIP0 = 2 * ABUF;     // skip rows behind the two buffers
     constexpr int SKIP_ROW = CPW * 4;   // bytes of a skip row: [32 hi | 32 lo] per 32 couts
     constexpr int SKIP_PPW = 4 * CB * PBW;  // 1 KiB pieces of the skip rows per loader wave
@@ -1060,7 +1066,7 @@ __global__ void __launch_bounds__(512, 2)
     const int cout0 = (logical % ncb) * CPW;
     const int row0 = (logical / ncb) * RW;
 
-    if (tid < 18) reinterpret_cast<f32x4*>(smem + (tid / 9) * ABUF + ZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 2 * (ZAREA_SP / 16)) reinterpret_cast<f32x4*>(smem + (tid / (ZAREA_SP / 16)) * ABUF + ZERO)[tid % (ZAREA_SP / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zero rows are written before the first barrier
 
     const int nch = cin / KC;
@@ -1236,7 +1242,8 @@ __global__ void __launch_bounds__(512, 2)
         for (int t9 = 0; t9 < 9; t9++) {
             const int hh = ph_ + t9 / 3 - 1, ww = pw + t9 % 3 - 1;
             const bool ok = pvalid && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
-            rowa[t9][pb] = (ok ? (board_row + hh * S + ww) * SP : ZERO) + h * 16;
+            const int at = (board_row + hh * S + ww) * SP + h * 16;  // off the board: only its low 8 bits are used
+            rowa[t9][pb] = ok ? at : ZERO + (at & 255);
         }
     }
 
@@ -1601,7 +1608,7 @@ constexpr int R_LDS_W = 0;                    // 3 x 24 KiB
 // loaders run one layer ahead and there is one barrier per layer instead of three; the consumer's fragment pipeline
 // runs through all 36 stages of the layer.  The two 8 KiB activation buffers fill the rest of the 160 KiB exactly, so
 // there is no room for zero rows: pixel slot 63, which such a board does not use, is kept zero and serves as one.
-constexpr int tower64_lds_bytes(int ch, bool ls) { return ls ? 6 * V2_SLAB + 2 * 64 * 128 : 3 * V2_SLAB + 2 * ((256 / ch) * 128 + 128); }
+constexpr int tower64_lds_bytes(int ch, bool ls) { return ls ? 6 * V2_SLAB + 2 * 64 * 128 : 3 * V2_SLAB + 2 * ((256 / ch) * 128 + 256); }
 
 template <int CH, bool BIG, bool LS = false>
 __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
@@ -1616,7 +1623,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     constexpr int NPB = CH == 4 ? 1 : 2; // 32-pixel blocks per consumer wave
     static_assert(!(BIG && CH == 4), "a 128-slot board needs 128 rows in one workgroup");
     constexpr int ZERO_OFF = LS ? 63 * 128 : ROWS * 128;    // the zero row of a buffer (padding pixels read it): behind its rows / slot 63
-    constexpr int ACT_BYTES = LS ? ROWS * 128 : ZERO_OFF + 128;  // buffer stride
+    constexpr int ACT_BYTES = LS ? ROWS * 128 : ZERO_OFF + 256;  // buffer stride (not LS: a 256-byte zero area, device_common.h)
     constexpr int SLOTS_PER_BOARD = BIG ? 128 : 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1630,7 +1637,7 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
     STAMP_DECL;
     STAMP(0);
 
-    if (tid < 16) reinterpret_cast<f32x4*>(smem + R_LDS_ACT + (tid >> 3) * ACT_BYTES + ZERO_OFF)[tid & 7] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < (LS ? 16 : 32)) reinterpret_cast<f32x4*>(smem + R_LDS_ACT + (tid / (LS ? 8 : 16)) * ACT_BYTES + ZERO_OFF)[tid % (LS ? 8 : 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int T_total = nlayers * 3;
     // the loader waves put the first two weight slabs on their way before they help with the plane expansion
@@ -1753,8 +1760,9 @@ __global__ void __launch_bounds__(512, 2) tower64_lds_kernel(Tower64Args A) {
                 const int hh = ph + g - 1, ww = pw + dxi - 1;
                 const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
                 const int q = hh * S + ww;
-                rel[g][dxi][pb] = ok ? board_lds + q * 128 : ZERO_OFF;
-                swz[g][dxi][pb] = ok ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
+                // off the board: the zero area at the row's own address mod 256 (LS has one zero row only: slot 63)
+                rel[g][dxi][pb] = ok ? board_lds + q * 128 : ZERO_OFF + (LS ? 0 : (q & 1) * 128);
+                swz[g][dxi][pb] = ok || !LS ? ((h ^ ((q >> 1) & 7)) << 4) : 0;
             }
     }
     int aaddr[4][CB];

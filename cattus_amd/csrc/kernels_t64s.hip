@@ -27,7 +27,9 @@ namespace cattus {
 // stand-alone launch) and write hv for the FC launch; optionally the f32 rows themselves go to HBM.
 constexpr int T64S_HP = 272;  // pitch of the f32 rows staged for the head convs, and of the head weight rows: 256 B + 16 (conflict-free b128 reads down rows)
 // two activation buffers | per layer [64 biases | 64 inverse scales] | head conv weights [32][64] f32 at pitch 272 | 32 head biases
-constexpr int t64s_lds_bytes(int npb, int nlayers) { return 2 * 2 * (64 * npb + 1) * SP + nlayers * 512 + 32 * T64S_HP + 128; }
+// behind a chunk image's rows: a zero area (device_common.h: with one zero row 37 % of this kernel's LDS cycles were bank conflicts on hex 7x7)
+constexpr int T64S_ZAREA = ZAREA_SP;
+constexpr int t64s_lds_bytes(int npb, int nlayers) { return 2 * 2 * (64 * npb * SP + T64S_ZAREA) + nlayers * 512 + 32 * T64S_HP + 128; }
 
 // D: weight stages in flight per wave (a stage is only 3 NPB MFMAs here, so the ring is deeper than the per-layer kernel's to
 // cover an L2 round trip); PA: stages of look-ahead on the pixel fragments.
@@ -44,8 +46,9 @@ __global__ void __launch_bounds__(256, 1) tower64_split_kernel(Tower64SplitArgs 
     static_assert(PA == 1 || PA == 2, "one or two stages of pixel look-ahead");
     constexpr int PR = PA + 1;  // pixel fragment ring; 18 % PR == 0 for both
     constexpr int ROWS = 64 * NPB;           // tower rows of this workgroup
-    constexpr int ZERO = ROWS * SP;          // a chunk image's zero row, behind its rows
-    constexpr int CHUNK = ZERO + SP;         // bytes of one 32-channel chunk image
+    constexpr int ZERO = ROWS * SP;          // a chunk image's zero area, behind its rows (a multiple of 256)
+    constexpr int CHUNK = ZERO + T64S_ZAREA; // bytes of one 32-channel chunk image
+    static_assert(ZERO % 256 == 0, "the zero area keeps a read's banks only if it is 256-B aligned inside the image");
     constexpr int BUF = 2 * CHUNK;           // an activation buffer: channels 0..31, 32..63
     constexpr int TABLE = 2 * BUF;           // per layer [64 biases | 64 inverse scales] behind the two buffers
     constexpr int SLOTS = BIG ? 128 : 64;    // pixel slots per board
@@ -102,8 +105,9 @@ __global__ void __launch_bounds__(256, 1) tower64_split_kernel(Tower64SplitArgs 
         for (int i = tid; i < 32 * 64; i += 256) *reinterpret_cast<float*>(smem + HEADW + (i >> 6) * T64S_HP + (i & 63) * 4) = A.head_w[i];
         if (tid < 32) *reinterpret_cast<float*>(smem + HEADB + tid * 4) = A.head_b[tid];
     }
-    // zero rows of the four chunk images
-    if (tid < 36) reinterpret_cast<f32x4*>(smem + (tid / 9) * CHUNK + ZERO)[tid % 9] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // zero areas of the four chunk images
+    if (tid < 4 * (T64S_ZAREA / 16))
+        reinterpret_cast<f32x4*>(smem + (tid / (T64S_ZAREA / 16)) * CHUNK + ZERO)[tid % (T64S_ZAREA / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- stem input: bitboard planes -> buffer 1, chunk 0: hi = 1.0 where the plane has the pixel's bit, lo = 0 ----
     {
         constexpr int SPT = ROWS * 4 / 256;  // 16-byte hi slots per thread (a row has 4: 32 channels)
@@ -143,7 +147,8 @@ __global__ void __launch_bounds__(256, 1) tower64_split_kernel(Tower64SplitArgs 
         for (int t9 = 0; t9 < 9; t9++) {
             const int hh = ph_ + t9 / 3 - 1, ww = pw + t9 % 3 - 1;
             const bool ok = pvalid[pb] && (unsigned)hh < (unsigned)S && (unsigned)ww < (unsigned)S;
-            rowa[t9][pb] = (ok ? (board_row + hh * S + ww) * SP : ZERO) + h * 16;
+            const int at = (board_row + hh * S + ww) * SP + h * 16;  // may lie outside the image when !ok: only its low 8 bits are used then
+            rowa[t9][pb] = ok ? at : ZERO + (at & 255);
         }
     }
     // epilogue addresses: this lane's accumulator element g * 4 + i is cout cb * 32 + g * 8 + h * 4 + i of pixel r: four
