@@ -41,6 +41,21 @@ namespace cattus {
 #ifndef WN_X_NOTRANSFORM
 #define WN_X_NOTRANSFORM 0
 #endif
+// WN_X_UMOD: cache-policy bits of the U ring's loads (" nt", " sc0", " sc1", ...: results unchanged)
+#ifndef WN_X_UMODE
+#define WN_X_UMODE 0
+#endif
+#if WN_X_UMODE == 1
+#define WN_X_UMOD " nt"
+#elif WN_X_UMODE == 2
+#define WN_X_UMOD " sc0"
+#elif WN_X_UMODE == 3
+#define WN_X_UMOD " sc1"
+#elif WN_X_UMODE == 4
+#define WN_X_UMOD " sc0 sc1"
+#else
+#define WN_X_UMOD ""
+#endif
 #ifndef WN_X_PLAINSTORE
 #define WN_X_PLAINSTORE 0
 #endif
@@ -108,7 +123,7 @@ __global__ void __launch_bounds__(256, 1)
     u32x4 ring[D][2];
     auto load_stage = [&](u32x4(&slot)[2], const char* p) __attribute__((always_inline)) {
         u32x4 l0, l1;
-        asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+        asm volatile("global_load_dwordx4 %0, %2, %3" WN_X_UMOD "\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" WN_X_UMOD
                      : "=&v"(l0), "=&v"(l1)
                      : "v"(voff0), "s"(p)
                      : "memory");
