@@ -76,7 +76,10 @@ constexpr int WN_DBUF = WN_DZERO + WN_ZAREA;  // 24,064 B
 static_assert(WN_DZERO % 256 == 0 && WN_DBUF % 256 == 0 && (2 * WN_VIMG) % 256 == 0, "the zero area keeps a read's banks only if it is 256-B aligned");
 constexpr int WN_LDS_D = 2 * WN_VIMG;
 constexpr int WN_LDS_TOTAL = WN_LDS_D + 2 * WN_DBUF;  // 130,048 B
-constexpr int WN_PA = 2;                   // stages of look-ahead on the V fragments
+#ifndef WN_X_PA
+#define WN_X_PA 2
+#endif
+constexpr int WN_PA = WN_X_PA;             // stages of look-ahead on the V fragments
 constexpr int WN_P = 5;                    // LDS-DMA pieces per wave and chunk: 4 x 5 = 20 >= the image's 19 KiB pieces
 
 // LDS-DMA of 64 x 16 bytes, hidden from the compiler (it would otherwise order this wave's later LDS reads behind a vmcnt(0) of
