@@ -56,6 +56,19 @@ __host__ __device__ constexpr size_t frag_packed_index(uint32_t row, uint32_t k,
     return ((((size_t)(row >> 5) * (K / KSTEP) + k / KSTEP) * 2 + (k % KSTEP) / HALF) * 32 + (row & 31)) * HALF + k % HALF;
 }
 
+// f32 rows that feed a Winograd layer: capped at WINO_ACT_MAX (kernels.h), values beyond it counted like note_saturation's.
+__device__ __forceinline__ void cap_wino_input(float (&y)[8], bool valid, unsigned* sat) {
+    const float m = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+    if (valid && m > WINO_ACT_MAX) {
+        unsigned n = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) n += y[j] > WINO_ACT_MAX ? 1u : 0u;
+        atomicAdd(sat, n);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) y[j] = y[j] < WINO_ACT_MAX ? y[j] : WINO_ACT_MAX;
+}
+
 // Off-board taps of the 3x3 kernels read zeros.  One zero ROW behind an image's rows put every such lane of a ds_read_b128 group on
 // one bank slot, colliding with whichever lane's real row shares it (a quarter of the conv kernels' LDS cycles were bank conflicts).
 // A zero AREA instead, 256-B aligned and read at (the off-board row's own address mod 256), gives the lane the banks its row would

@@ -715,7 +715,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             auto wptr = [&](const ConvLayer& c) { return wfrag ? c.wf.p : c.w.p; };
             launch_conv3x3_mfma(e->act, L.x0.p, wptr(e->stem), e->stem.b.as<float>(), nullptr, a, nb, e->cpad0, FP, S, st, s0, s1,
                                 fused_stem ? &stem_in : nullptr,
-                                wflag | (d.blocks == 0 || (e->act == Act::F16S && e->c1[0]->wu.p) ? last_flags : 0), e->conv_opts);
+                                wflag | (d.blocks == 0 ? last_flags : e->act == Act::F16S && e->c1[0]->wu.p ? CONV_OUT_F32 | CONV_WINO_IN : 0), e->conv_opts);
             // f16x2 with CATTUS_WINOGRAD=1 on 8x8 boards: every layer behind the stem in Winograd form, f32 rows between the layers
             const bool wino = d.blocks > 0 && e->c1[0]->wu.p != nullptr;
             auto conv = [&](const ConvLayer& c, const void* in, const void* res, void* out, int lflags) {

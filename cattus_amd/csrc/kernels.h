@@ -57,7 +57,11 @@ struct StemInput {
 // flags & CONV_W_FRAG (F16S only): w is in MFMA fragment order, [cout / 32][stage][hi | lo][lane][8 f16] with
 // stage = ((chunk * 3 + dy) * 3 + dx) * 2 + k-half (split_frag_index below): the kernel that keeps the weights in a register
 // ring instead of LDS.  Non-stem layers then need cin >= 64.
-constexpr int CONV_OUT_F32 = 1, CONV_W_FRAG = 2;
+// flags & CONV_WINO_IN (with CONV_OUT_F32): the rows feed a Winograd tower (K1w): values are capped at WINO_ACT_MAX and counted in
+// `sat` beyond it -- a transformed input B^T d B is a signed sum of four activations, so no |V| can leave the f16 range then and the
+// Winograd kernel's transform needs neither a clamp nor a range check of its own.
+constexpr int CONV_OUT_F32 = 1, CONV_W_FRAG = 2, CONV_WINO_IN = 4;
+constexpr float WINO_ACT_MAX = 16376.0f;  // 65504 / 4, exactly
 // Element index of weight (tap t, output channel co, input channel ci, part 0 = hi / 1 = lo) in fragment order.
 inline size_t split_frag_index(uint32_t t, uint32_t co, uint32_t ci, uint32_t part, uint32_t cin_pad) {
     const uint32_t nst = cin_pad / 32 * 18, ch = ci >> 5, k = (ci >> 4) & 1, h = (ci >> 3) & 1, e = ci & 7;

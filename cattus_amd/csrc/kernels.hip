@@ -973,7 +973,8 @@ __global__ void __launch_bounds__(512, 2)
                 y[j] = v[j] > 0.0f ? v[j] : 0.0f;
                 if (!valid) y[j] = 0.0f;
             }
-            if (flags & CONV_OUT_F32) {  // the tower's last layer: plain f32 rows for the head kernels
+            if (flags & CONV_OUT_F32) {  // the tower's last layer: plain f32 rows for the head kernels (or a Winograd tower's stem)
+                if (flags & CONV_WINO_IN) cap_wino_input(y, true, sat);
                 float* of = reinterpret_cast<float*>(out) + (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
                 __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y), reinterpret_cast<f32x4*>(of));
                 __builtin_nontemporal_store(*reinterpret_cast<f32x4*>(y + 4), reinterpret_cast<f32x4*>(of) + 1);
@@ -1369,6 +1370,7 @@ __global__ void __launch_bounds__(512, 2)
             for (int j = 0; j < 8; j++) y[j] = v[j] > 0.0f ? v[j] : 0.0f;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             if (flags & CONV_OUT_F32) {
+                if (flags & CONV_WINO_IN) cap_wino_input(y, valid, sat);
                 float* of = reinterpret_cast<float*>(out) + (wrow0 + px) * (size_t)cout + cout0 + cg * 8;
                 const f32x4 y0 = valid ? *reinterpret_cast<f32x4*>(y) : zero4, y1 = valid ? *reinterpret_cast<f32x4*>(y + 4) : zero4;
                 if constexpr (CB == 2) {

@@ -15,7 +15,9 @@
 // (every layer but the stem): between its layers the activations are PLAIN F32 rows [row][channel] -- what the split tower's last
 // layer writes for the heads anyway (CONV_OUT_F32), so the stem is the direct kernel with that flag and the heads do not change.
 // The input transform then reads f32 (no hi + lo reassembly: 5 of its 21 instructions per value) and the epilogue writes f32 (no
-// split, no clamp); only the transformed operands U and V are (hi, lo) pairs.
+// split); only the transformed operands U and V are (hi, lo) pairs.  The f16 range: a transformed input is a signed sum of four
+// activations, so activations are capped at WINO_ACT_MAX = 65504 / 4 where they are written (this kernel's epilogue, the stem's
+// CONV_WINO_IN) and counted there; the transform itself needs no clamp.
 //   workgroup = 4 waves = 2 boards (32 tiles) x 128 couts; wave w holds the 16 accumulators of (32 tiles, couts 32w .. 32w+31)
 //   U (weights): G g G^T in float64 on the host, scaled per cout by a power of two, split (hi, lo), in MFMA fragment order
 //       [cout / 32][k-step x 16 + f][hi | lo][lane][8 f16]; from L2 straight into a register ring, WN_D stages ahead
@@ -24,7 +26,7 @@
 //       (hi, lo) and writes them to the k-step's V image [f][tile][16 ch hi | 16 ch lo]; sliced between the MFMA stages of the
 //       previous k-step, two images
 //   a stage = (k-step of 16 channels, frequency f): 2 ring fragments + 2 ds_read_b128 -> 3 MFMAs into accumulator f
-//   epilogue: Y = A^T M A in registers (per lane: tile r, 16 couts), * 2^-s + bias, + skip, ReLU, clamp, split, stores.
+//   epilogue: Y = A^T M A in registers (per lane: tile r, 16 couts), * 2^-s + bias, + skip, ReLU, cap, f32 stores.
 #include "kernels.h"
 #include "device_common.h"
 
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(256, 1)
     const int mr0 = ((tt >> 2) & 3) != 0 ? -1 : 255, mr3 = ((tt >> 2) & 3) != 3 ? -1 : 255, mc0 = (tt & 3) != 0 ? -1 : 255, mc3 = (tt & 3) != 3 ? -1 : 255;
     const int vwr = tt * WN_VP + chp * 4;  // where this item's hi pair goes inside a frequency's block (the lo pair 32 further)
     f32x2 dd[16];                          // the patch as f32, then (in place) B^T d, then B^T d B
-    float vmax = 0.0f;                     // largest |V| this thread has seen
+    float vmax = 0.0f;                     // largest activation this thread has written
     // kp: which half (16 channels) of the chunk; slices 0..3 read a patch row each, 4..7 do the row transform of a column,
     // 8..15 the column transform of half a row each: two frequencies split into (hi, lo) and written.
     // A slice comes in two parts, issued behind the first and the second MFMA of its stage: the wave issues in order and the three
@@ -199,9 +201,8 @@ __global__ void __launch_bounds__(256, 1)
             const int i = (slice - 8) >> 1, l = ((slice - 8) & 1) * 2 + part;
             const f32x2 t0 = dd[i * 4], t1 = dd[i * 4 + 1], t2 = dd[i * 4 + 2], t3 = dd[i * 4 + 3];
             f32x2 x = l == 0 ? t0 - t2 : l == 1 ? t1 + t2 : l == 2 ? t2 - t1 : t1 - t3;
-            // the f16 range is left HERE in this tower (activations are f32): saturate rather than overflow, and count it
-            vmax = fmaxf(fmaxf(vmax, fabsf(x[0])), fabsf(x[1]));  // one v_max3: checked once, at the end
-            x = __builtin_elementwise_min(__builtin_elementwise_max(x, f32x2{-65504.0f, -65504.0f}), f32x2{65504.0f, 65504.0f});
+            // |x| <= 65504: x is a signed sum of four activations, and whoever wrote those capped them at WINO_ACT_MAX = 65504 / 4
+            // (this kernel's epilogue, the stem's CONV_WINO_IN) -- no clamp, no range check among the loop's instructions
             const f16x2v hi = __builtin_convertvector(x, f16x2v);
             // lo = f16(x - hi): the difference is exact in f32 (hi is x rounded to 11 bits), so one mixed-precision fma per element
             // (v_fma_mixlo/hi_f16: f16 operand in, f32 arithmetic, f16 out) gives the bits of convert - subtract - convert
@@ -365,8 +366,10 @@ __global__ void __launch_bounds__(256, 1)
             // the inverse weight scale is a power of two: the product is exact, the fma rounds once
             float x = __builtin_fmaf(a[j], ds4[j], bias4[j]);
             if (HAS_RES) x = x + skip[k][j];
-            v[j] = x > 0.0f ? x : 0.0f;
+            x = x > 0.0f ? x : 0.0f;
+            v[j] = x < WINO_ACT_MAX ? x : WINO_ACT_MAX;  // the next layer's transform relies on it (and counts nothing itself)
         }
+        vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
         if (WN_X_NOSTORE && v[0] != 12345.678f) continue;
         f32x4* dst = reinterpret_cast<f32x4*>(out + ((size_t)row0 + px) * (size_t)cout + cout0 + pc * 4);
         if (WN_X_PLAINSTORE) {
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(256, 1)
         }
         __builtin_nontemporal_store(v, dst);
     }
-    if (vmax > 65504.0f) atomicAdd(sat, 1u);  // a transformed input left the f16 range somewhere in this thread's share
+    if (vmax >= WINO_ACT_MAX) atomicAdd(sat, 1u);  // an activation reached the cap somewhere in this thread's share
 }
 
 bool wino_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S) {
