@@ -68,8 +68,8 @@ typedef struct cattus_stats {
     uint64_t full_batches;  /* batches that ran with n == max_batch */
     double run_seconds_ema; /* == reference metric model.run_duration (EMA 0.99, util/metric.rs:16-19) */
     double run_seconds_total;
-    /* f16x2 / f16 towers: activation values that exceeded the f16 range (65504) and were clamped, since the evaluator was
-     * created (sticky).  0 for every network inside the range; > 0 means outputs of this evaluator are NOT the network's:
+    /* f16x2 / f16 towers: activation values that exceeded the f16 range (65504; in the Winograd form of the f16x2 tower a
+     * quarter of it, 16376: its transformed inputs are sums of four) and were clamped, since the evaluator was created (sticky).  0 for every network inside the range; > 0 means outputs of this evaluator are NOT the network's:
      * use dtype f32 for that network (a BatchNorm scale of 1e5 does it; one of 200 does not). */
     uint64_t saturated;
 } cattus_stats;

@@ -722,7 +722,8 @@ def test_winograd_tower_tracks_the_f32_tower_at_full_size(net, n, bound):
 
 def test_winograd_tower_counts_inputs_that_leave_the_f16_range():
     """The Winograd tower keeps f32 activations; what leaves the f16 range there is a TRANSFORMED input (up to four times an
-    activation).  It is clamped and counted like the direct tower's activations: 0 for a BatchNorm scale of 200, > 0 for 1e5."""
+    activation), so activations are capped at 65504 / 4 where they are written and counted like the direct tower's: 0 for a
+    BatchNorm scale of 200, > 0 for 1e5."""
     from cattus_amd.weights import pack_tensors, seeded_tensors
 
     d = NetDesc(**CHESS, blocks=2, filters=128, vhc=8, phc=8)
