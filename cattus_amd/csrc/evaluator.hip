@@ -101,19 +101,44 @@ Folded fold_conv(const float* w, uint32_t cout, uint32_t cin, uint32_t taps, con
     return f;
 }
 
+// One device allocation that a tower's hot buffers are carved from (the Winograd tower: the transformed weights of all layers and
+// the activation buffers).  What a forward pass of chess 20x256 touches -- 168 MB of U, 50 MB of activations -- is most of the 256 MB
+// Infinity Cache, which is indexed by physical address: 110 separately allocated 2 MB pages land on its sets unevenly, some sets
+// overflow, and the weight stream then comes from HBM in part (the same binary ran a layer in 31 or in 34 us from one process to
+// the next, and towers of <= 17 blocks always in 31).  One contiguous block covers the sets evenly.
+struct DevArena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    ~DevArena() {
+        if (base) (void)hipFree(base);
+    }
+    void* take(size_t bytes) {  // nullptr when it does not fit (or there is no arena): the caller allocates on its own
+        const size_t at = (used + 4095) & ~(size_t)4095;
+        if (!base || at + bytes > cap) return nullptr;
+        used = at + bytes;
+        return base + at;
+    }
+};
+
 struct DevBuf {
     void* p = nullptr;
+    bool owned = true;  // false: carved from a DevArena, which frees it
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
     }
-    int alloc(size_t bytes) {
-        if (p) (void)hipFree(p), p = nullptr;
+    int alloc(size_t bytes, DevArena* arena = nullptr) {
+        if (p && owned) (void)hipFree(p);
+        p = nullptr, owned = true;
+        if (arena && (p = arena->take(bytes ? bytes : 16))) {
+            owned = false;
+            return CATTUS_OK;
+        }
         hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
         if (e != hipSuccess) return fail(CATTUS_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return CATTUS_OK;
     }
-    int upload(const void* src, size_t bytes) {
-        int rc = alloc(bytes);
+    int upload(const void* src, size_t bytes, DevArena* arena = nullptr) {
+        int rc = alloc(bytes, arena);
         if (rc) return rc;
         HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
         return CATTUS_OK;
@@ -226,6 +251,7 @@ struct Lane {
 }  // namespace
 
 struct cattus_eval {
+    DevArena arena;  // first member: destroyed last, behind every buffer carved from it
     cattus_net_desc d{};
     cattus_eval_config cfg{};
     bool tuned = false;  // MFMA NHWC tower vs generic NCHW f32 tower
@@ -391,7 +417,7 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
                     }
             }
             if ((rc = L.bw.upload(bwv.data(), bwv.size() * sizeof(float)))) return rc;
-            if ((rc = L.wu.upload(wu.data(), wu.size() * 2))) return rc;
+            if ((rc = L.wu.upload(wu.data(), wu.size() * 2, &e->arena))) return rc;
         }
         if (e->split_wfrag) {  // the register-ring kernel's layout: a permutation of the rows above
             std::vector<_Float16> wf(w.size());
@@ -624,9 +650,9 @@ int build(cattus_eval* e, const float* p) {
         HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventBlockingSync | hipEventDisableTiming));
         if ((rc = L.d_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
         if ((rc = L.x0.alloc(bp_ * slots * e->cpad0 * esz))) return rc;
-        if ((rc = L.a.alloc(bp_ * slots * FA * esz))) return rc;
-        if ((rc = L.t.alloc(bp_ * slots * FA * esz))) return rc;
-        if ((rc = L.y.alloc(bp_ * slots * FA * esz))) return rc;
+        if ((rc = L.a.alloc(bp_ * slots * FA * esz, &e->arena))) return rc;
+        if ((rc = L.t.alloc(bp_ * slots * FA * esz, &e->arena))) return rc;
+        if ((rc = L.y.alloc(bp_ * slots * FA * esz))) return rc;  // the Winograd tower does not touch it (its blocks write in place)
         const size_t hv_bytes = (size_t)(e->tuned ? (bp_ + 31) / 32 * 32 : bp_) * (e->kvp + e->kpp) * hesz;  // tuned: whole 32-leaf tiles
         if ((rc = L.hv.alloc(hv_bytes))) return rc;
         HIP_TRY(hipMemset(L.hv.p, 0, hv_bytes));  // pad columns (and leaves never written) must read as zero
@@ -725,6 +751,13 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             };
             for (uint32_t i = 0; i < d.blocks; i++) {
                 conv(*e->c1[i], a, nullptr, t, 0);
+                if (wino) {
+                    // the block's output over its own skip rows, in place: the lane that adds a skip element is the lane that writes
+                    // that element, behind all its reads -- two activation buffers instead of three (33.6 instead of 50 MB per lane
+                    // of what a pass drags through the Infinity Cache beside the 168 MB of U)
+                    conv(*e->c2[i], t, a, a, 0);
+                    continue;
+                }
                 conv(*e->c2[i], t, a, y, i + 1 == d.blocks ? last_flags : 0);
                 std::swap(a, y);
             }
@@ -1039,6 +1072,18 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->fpad = e->tuned ? (d.filters + COUT_PER_WG - 1) / COUT_PER_WG * COUT_PER_WG : d.filters;
     const uint32_t bpw = e->tuned ? ROWS_PER_WG / e->slots : 1;
     e->bpad = (cfg->max_batch + bpw - 1) / bpw * bpw;
+    const char* arena_env = getenv("CATTUS_ARENA");  // 0: every buffer its own allocation (A/B runs)
+    if (e->tuned && e->act == Act::F16S && e->winograd && d.blocks > 0 && wino_supported(e->bpad, e->fpad, e->fpad, d.board) &&
+        !(arena_env && arena_env[0] == '0')) {
+        // the Winograd tower's hot set in one block: U of every layer, then the lanes' activation buffers (DevArena)
+        auto page = [](size_t b) { return (b + 4095) & ~(size_t)4095; };
+        const size_t FPz = e->fpad, u_bytes = page(((size_t)16 * FPz * FPz * 2 + (size_t)WINO_RING_STAGES * 1024) * 2);
+        const size_t act_bytes_ = page((size_t)e->bpad * e->slots * FPz * 4);
+        const size_t want = 2 * (size_t)d.blocks * u_bytes + (size_t)NLANES * 2 * act_bytes_ + (1u << 20);
+        void* base = nullptr;
+        if (hipMalloc(&base, want) == hipSuccess) e->arena.base = (char*)base, e->arena.cap = want;
+        else (void)hipGetLastError();  // no room for one block: separate allocations, as before
+    }
     int rc = build(e.get(), reinterpret_cast<const float*>((const char*)weights + HEADER_BYTES));
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());

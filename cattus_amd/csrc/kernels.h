@@ -85,7 +85,8 @@ void launch_conv3x3_mfma(Act act, const void* in, const void* w, const float* bi
 // 8x8 boards only; in / res / out are PLAIN F32 rows [row][channel] (what CONV_OUT_F32 writes: a tower in this form keeps f32
 // activations between its layers); wu = G g G^T as (hi, lo) f16 pairs pre-scaled per output channel, in fragment order
 // [cout / 32][(cin / 16) k-steps x 16 frequencies][hi | lo][lane][8 f16] (wino_frag_index); bias = [cout biases | cout inverse
-// scales] of THAT scaling; sat: counts threads whose transformed inputs left the f16 range.
+// scales] of THAT scaling; res may be out (a block's output over its skip rows); outputs are capped at WINO_ACT_MAX and sat counts
+// the threads that wrote the cap.
 // the kernel's weight ring reads WINO_RING_STAGES stages (of 2,048 B) past a cout block's end: wu is allocated with that much behind it
 constexpr int WINO_RING_STAGES = 8;
 bool wino_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S);

@@ -43,7 +43,19 @@ namespace cattus {
 #ifndef WN_X_NOTRANSFORM
 #define WN_X_NOTRANSFORM 0
 #endif
-// WN_X_UMOD: cache-policy bits of the U ring's loads (" nt", " sc0", " sc1", ...: results unchanged)
+// WN_X_AMOD: the same for the LDS-DMA of the activation chunks.  WN_X_UMOD: cache-policy bits of the U ring's loads (" nt", " sc0", " sc1", ...: results unchanged)
+#ifndef WN_X_AMODE
+#define WN_X_AMODE 0
+#endif
+#if WN_X_AMODE == 1
+#define WN_X_AMOD " nt"
+#elif WN_X_AMODE == 2
+#define WN_X_AMOD " sc1"
+#elif WN_X_AMODE == 3
+#define WN_X_AMOD " sc0 sc1"
+#else
+#define WN_X_AMOD ""
+#endif
 #ifndef WN_X_UMODE
 #define WN_X_UMODE 0
 #endif
@@ -88,7 +100,7 @@ constexpr int WN_P = 5;                    // LDS-DMA pieces per wave and chunk:
 // its own, which also waits for the whole register ring): M0 = the wave-uniform LDS byte address, each lane its own source.
 __device__ __forceinline__ void glds16_asm(const char* gsrc, uint32_t lds_dst) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" WN_X_AMOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
@@ -101,7 +113,9 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4v;
 template <bool HAS_RES>
 __global__ void __launch_bounds__(256, 1)
     conv3x3_wino_kernel(const float* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
-                        const float* __restrict__ res, float* __restrict__ out, unsigned* __restrict__ sat, int cin, int cout) {
+                        const float* res, float* out, unsigned* __restrict__ sat, int cin, int cout) {
+    // res and out may be the same rows (a residual block's output over its skip rows): an element's skip value is read and its
+    // result written by one lane, the read first
     typedef _Float16 T;
     typedef Mfma<T>::frag frag;
     constexpr int D = WN_D;

@@ -19,7 +19,7 @@ from cattus_amd.evaluator import LIB_PATH, HipEvaluator  # noqa: E402
 from cattus_amd.weights import CHESS, NetDesc, seeded_blob  # noqa: E402
 
 out = {"lib": str(LIB_PATH)}
-CASES = ((20, 256, 256, 2), (4, 128, 192, 5), (40, 384, 512, 3))
+CASES = ((20, 256, 256, 2), (4, 128, 192, 5), (40, 384, 512, 3), (10, 256, 256, 2), (5, 256, 256, 2), (15, 256, 256, 2), (17, 256, 256, 2), (24, 256, 256, 2), (30, 256, 256, 2))
 if len(sys.argv) > 1:  # e.g. "0" = the bench net only
     CASES = tuple(CASES[int(a)] for a in sys.argv[1:])
 for blocks, filters, n, seed in CASES:
