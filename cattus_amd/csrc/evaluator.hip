@@ -280,6 +280,7 @@ struct cattus_eval {
     // in: for max_batch >= 192 (below that the direct kernels' small tiles win: 14 against 33 us per launch at 64 leaves of chess
     // 20x256, 42.8 against 37.5 at 256); CATTUS_WINOGRAD=0 / 1 forbids / forces it.
     bool winograd = false;
+    bool wino_inplace = true;      // CATTUS_WINO_INPLACE=0: a third activation buffer for the blocks' outputs (A/B runs)
     bool split_wfrag = true;       // CATTUS_SPLIT_W=0: f16x2 weights through the LDS ring (conv3x3_split_kernel) instead of the register ring
     // tile-forcing switches (CATTUS_CONV_CB, CATTUS_CONV_PBW: A/B runs, the tile-equality tests) and the f16 towers' saturation
     // counter: this evaluator's own -- a second evaluator in the process (model1 vs model2) neither re-tiles nor shares them
@@ -652,7 +653,7 @@ int build(cattus_eval* e, const float* p) {
         if ((rc = L.x0.alloc(bp_ * slots * e->cpad0 * esz))) return rc;
         if ((rc = L.a.alloc(bp_ * slots * FA * esz, &e->arena))) return rc;
         if ((rc = L.t.alloc(bp_ * slots * FA * esz, &e->arena))) return rc;
-        if ((rc = L.y.alloc(bp_ * slots * FA * esz))) return rc;  // the Winograd tower does not touch it (its blocks write in place)
+        if ((rc = L.y.alloc(bp_ * slots * FA * esz, e->wino_inplace ? nullptr : &e->arena))) return rc;  // in place: the Winograd tower does not touch it
         const size_t hv_bytes = (size_t)(e->tuned ? (bp_ + 31) / 32 * 32 : bp_) * (e->kvp + e->kpp) * hesz;  // tuned: whole 32-leaf tiles
         if ((rc = L.hv.alloc(hv_bytes))) return rc;
         HIP_TRY(hipMemset(L.hv.p, 0, hv_bytes));  // pad columns (and leaves never written) must read as zero
@@ -751,7 +752,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             };
             for (uint32_t i = 0; i < d.blocks; i++) {
                 conv(*e->c1[i], a, nullptr, t, 0);
-                if (wino) {
+                if (wino && e->wino_inplace) {
                     // the block's output over its own skip rows, in place: the lane that adds a skip element is the lane that writes
                     // that element, behind all its reads -- two activation buffers instead of three (33.6 instead of 50 MB per lane
                     // of what a pass drags through the Infinity Cache beside the 168 MB of U)
@@ -1072,6 +1073,8 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->fpad = e->tuned ? (d.filters + COUT_PER_WG - 1) / COUT_PER_WG * COUT_PER_WG : d.filters;
     const uint32_t bpw = e->tuned ? ROWS_PER_WG / e->slots : 1;
     e->bpad = (cfg->max_batch + bpw - 1) / bpw * bpw;
+    const char* inplace_env = getenv("CATTUS_WINO_INPLACE");
+    e->wino_inplace = !(inplace_env && inplace_env[0] == '0');
     const char* arena_env = getenv("CATTUS_ARENA");  // 0: every buffer its own allocation (A/B runs)
     if (e->tuned && e->act == Act::F16S && e->winograd && d.blocks > 0 && wino_supported(e->bpad, e->fpad, e->fpad, d.board) &&
         !(arena_env && arena_env[0] == '0')) {
@@ -1079,7 +1082,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
         auto page = [](size_t b) { return (b + 4095) & ~(size_t)4095; };
         const size_t FPz = e->fpad, u_bytes = page(((size_t)16 * FPz * FPz * 2 + (size_t)WINO_RING_STAGES * 1024) * 2);
         const size_t act_bytes_ = page((size_t)e->bpad * e->slots * FPz * 4);
-        const size_t want = 2 * (size_t)d.blocks * u_bytes + (size_t)NLANES * 2 * act_bytes_ + (1u << 20);
+        const size_t want = 2 * (size_t)d.blocks * u_bytes + (size_t)NLANES * (e->wino_inplace ? 2 : 3) * act_bytes_ + (1u << 20);
         void* base = nullptr;
         if (hipMalloc(&base, want) == hipSuccess) e->arena.base = (char*)base, e->arena.cap = want;
         else (void)hipGetLastError();  // no room for one block: separate allocations, as before
