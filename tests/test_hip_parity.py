@@ -702,6 +702,31 @@ def test_winograd_tower_within_the_reference_tolerance_and_batch_independent(mon
     assert np.abs(p - pd).max() < 2e-6 and np.abs(v - vd).max() < 1e-6  # the two forms of the same tower
 
 
+def test_winograd_tower_memory_plans_agree_bit_for_bit(monkeypatch):
+    """The Winograd tower carves U of all layers and its activation buffers from one contiguous allocation (Infinity Cache page
+    colouring) and writes a residual block's output over its own skip rows (two activation buffers per lane).
+    Neither may change a bit: separate allocations (CATTUS_ARENA=0) and a third buffer (CATTUS_WINO_INPLACE=0) give the same
+    outputs, on both lanes, for a full and for a ragged batch."""
+    d = NetDesc(**CHESS, blocks=3, filters=128, vhc=8, phc=8)
+    blob = seeded_blob(d, 11)
+    planes = synth.random_chess_planes(256, 12)
+    got = {}
+    for arena, inplace in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("CATTUS_ARENA", arena)
+        monkeypatch.setenv("CATTUS_WINO_INPLACE", inplace)
+        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
+            assert ev.tower_kernel() == "conv3x3_wino_kernel"
+            a = ev.eval(planes)
+            b = ev.eval(planes[:77])  # the second call takes the other lane's buffers when the first one's are still warm
+            c = ev.eval(planes)
+            assert ev.stats()["saturated"] == 0
+        assert (a[0] == c[0]).all() and (a[1] == c[1]).all() and (b[0] == a[0][:77]).all() and (b[1] == a[1][:77]).all()
+        got[arena, inplace] = a
+    ref = got["1", "1"]
+    for k, v in got.items():
+        assert (v[0] == ref[0]).all() and (v[1] == ref[1]).all(), k
+
+
 @pytest.mark.parametrize("net,n,bound", [("20x256", 256, (3e-6, 1e-6)), ("40x384", 512, (1.2e-5, 2e-6))])
 def test_winograd_tower_tracks_the_f32_tower_at_full_size(net, n, bound):
     """BASELINE configs 3 and 5 at full size in Winograd form against the bit-exact f32 tower, under the bounds the direct split
