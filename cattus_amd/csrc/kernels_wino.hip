@@ -8,8 +8,9 @@
 // the loop below without its transforms runs 21-23 us per 256 -> 256 layer at batch 256 where the direct loop takes 36 on the
 // same harness).  The price is operand traffic: a wave has to hold all 16 accumulators of its (32 tiles x 32 couts) block until the
 // output transform -- 256 registers -- so there is no room for a second block and every operand fragment feeds one accumulator:
-// 1.33 KiB of fragments per MFMA (the direct kernel: 0.67).  The loop is operand-bound at about half of the MFMA rate, and still
-// 1.6x shorter than the direct loop.
+// 1.33 KiB of fragments per MFMA (the direct kernel: 0.67).  The loop is bound by the U stream -- 2 MB per CU and layer through the
+// 64 B/clk vector-memory return path, 19.7 us under the MFMAs in the probe where the MFMAs alone take 12.2 -- and still 1.6x shorter
+// than the direct loop.
 //
 // Shape: 8x8 boards (64 pixel slots, 16 tiles of 2x2), cin and cout multiples of 64 / 128.  A tower runs in this form as a whole
 // (every layer but the stem): between its layers the activations are PLAIN F32 rows [row][channel] -- what the split tower's last
@@ -22,9 +23,9 @@
 //   U (weights): G g G^T in float64 on the host, scaled per cout by a power of two, split (hi, lo), in MFMA fragment order
 //       [cout / 32][k-step x 16 + f][hi | lo][lane][8 f16]; from L2 straight into a register ring, WN_D stages ahead
 //   d (activations): 32-channel chunks of the 128 pixel rows by LDS-DMA (asm: the compiler neither sees nor counts them), two buffers
-//   V = B^T d B: every thread transforms one (tile, channel pair) per k-step, in f32 on d = hi + lo, splits the 16 values into
-//       (hi, lo) and writes them to the k-step's V image [f][tile][16 ch hi | 16 ch lo]; sliced between the MFMA stages of the
-//       previous k-step, two images
+//   V = B^T d B: every thread transforms one (tile, channel pair) per k-step in f32, splits the 16 values into (hi, lo) and writes
+//       them to the k-step's V image [f][tile][16 ch hi | 16 ch lo]; sliced over the 16 MFMA stages of the previous k-step, each slice
+//       in two parts BETWEEN the stage's three MFMAs; a half wave = 8 tiles x 4 channel pairs (no LDS bank conflicts); two images
 //   a stage = (k-step of 16 channels, frequency f): 2 ring fragments + 2 ds_read_b128 -> 3 MFMAs into accumulator f
 //   epilogue: Y = A^T M A in registers (per lane: tile r, 16 couts), * 2^-s + bias, + skip, ReLU, cap, f32 stores.
 #include "kernels.h"
