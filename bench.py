@@ -274,9 +274,10 @@ TRAFFIC_FILE = "profiles/r04_pmc_hbm_traffic.json"
 
 def kernels_sha256() -> str:
     """Identity of the kernel CODE the traffic counters were collected on: sha256 of the kernel sources (device_common.h,
-    kernels.hip, kernels_t64s.hip) with their `//` comments and all white space removed (an edited comment does not make a
-    measurement stale; the files have no block comments and no `//` inside a string literal)."""
-    text = "".join((ROOT / "cattus_amd" / "csrc" / name).read_text() for name in ("device_common.h", "kernels.hip", "kernels_t64s.hip"))
+    kernels.h, kernels.hip, kernels_t64s.hip, kernels_wino.hip) with their `//` comments and all white space removed (an edited
+    comment does not make a measurement stale; the files have no block comments and no `//` inside a string literal)."""
+    names = ("device_common.h", "kernels.h", "kernels.hip", "kernels_t64s.hip", "kernels_wino.hip")
+    text = "".join((ROOT / "cattus_amd" / "csrc" / name).read_text() for name in names)
     code = "".join("".join(line.split("//", 1)[0].split()) for line in text.splitlines())
     return hashlib.sha256(code.encode()).hexdigest()
 
