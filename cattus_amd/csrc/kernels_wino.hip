@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256, 1)
     // pixels x 32 couts go through LDS as f32 (the V images are free now: 16 KiB per wave, 16-byte slots XOR-swizzled by the pixel) and
     // come back as (pixel, 8 consecutive couts) per lane -- whole 64-byte runs per store instruction, the direct kernel's epilogue.
     // (Written straight from the accumulator layout the output is 32 eight-byte stores per lane: 11.6 of 48 us.)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the V images
+    // (no barrier here: every wave left the V images, which the transpose reuses, behind the last k-step's barrier)
     char* stage = smem + wave * 16384;
     const int board = er >> 4, ty = (er >> 2) & 3, tx = er & 3;
     // Final layout: lane = (pixel k * 8 + (lane >> 3), couts 4 pc .. 4 pc + 3 with pc = lane & 7): eight lanes cover a pixel's 128 bytes
