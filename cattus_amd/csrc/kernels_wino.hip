@@ -166,6 +166,23 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
         for (int i = 0; i < WN_P; i++) glds16_asm(src + off_a[i], dst + dst_a[i]);
     };
+    // The layer's last two DMA issues have no chunk left to fetch (they re-read the last one so that the count of loads in flight stays
+    // fixed).  With skip rows they fetch HALF OF THE SKIP TILE instead, in the epilogue's final layout (piece = k-iteration k of this wave:
+    // lane = (pixel k * 8 + (lane >> 3), couts 4 (lane & 7) ..)): k = 0..3 into the buffer the first of them overwrites, 4..7 into the
+    // other's; the fifth instruction of a wave repeats its fourth.  Same instructions at the same places -- the wait counts do not change --
+    // and the epilogue asks the fabric for half as many skip bytes at the moment every workgroup of the chip asks.
+    uint32_t off_s[WN_P];
+#pragma unroll
+    for (int i = 0; i < WN_P; i++) off_s[i] = (uint32_t)((min(i, 3) * 8 + (lane >> 3)) * cout) * 4 + (lane & 7) * 16;
+    const char* sbase0 = reinterpret_cast<const char*>(res) + ((size_t)row0 * cout + cout0) * 4;
+    auto issue_chunk_or_skip = [&](int c) __attribute__((always_inline)) {
+        const int sl = c - (nch - 2);  // 0, 1: the last two issues
+        const bool sk = HAS_RES && sl >= 0;
+        const char* src = sk ? sbase0 + (size_t)sl * 32 * cout * 4 : abase0 + (size_t)min(c + 2, nch - 1) * 128;
+        const uint32_t dst = WN_LDS_D + (c & 1) * WN_DBUF;
+#pragma unroll
+        for (int i = 0; i < WN_P; i++) glds16_asm(src + (sk ? off_s[i] : off_a[i]), dst + dst_a[i]);
+    };
     for (int i = tid; i < 2 * (WN_ZAREA / 16); i += 256)  // the two zero areas
         reinterpret_cast<f32x4*>(smem + WN_LDS_D + (i / (WN_ZAREA / 16)) * WN_DBUF + WN_DZERO)[i % (WN_ZAREA / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
     // chunk 0 goes out first, then the ring's first D stages, then chunk 1: V of k-step 0 needs chunk 0 alone and is made while the rest
@@ -308,7 +325,7 @@ __global__ void __launch_bounds__(256, 1)
         // k-step 2c on image 0; meanwhile V of k-step 2c + 1 (the chunk's second half) -> image 1
         kstep(wchunk, 0, dcur, 1, WN_VIMG, std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // image 1 is complete, image 0 and chunk c are free
-        issue_chunk(min(c + 2, nch - 1), c & 1);                           // -> the buffer chunk c was in (past the end: a re-read nobody uses)
+        issue_chunk_or_skip(c);  // chunk c + 2 -> the buffer chunk c was in; the last two issues: half of the skip tile (or a re-read nobody uses)
         // k-step 2c + 1 on image 1; meanwhile V of k-step 2c + 2 (the next chunk's first half) -> image 0
         kstep(wchunk, WN_VIMG, dnext, 0, 0, std::integral_constant<int, 16>{});
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -343,9 +360,10 @@ __global__ void __launch_bounds__(256, 1)
     // the skip rows: requested AHEAD of the output transform (the ring's 64 registers are free from the drain on), used behind the
     // transpose: their latency hides behind the transform's ~800 VALU instructions
     f32x4 skip[16];
+    constexpr int SK0 = 8;  // k-iterations whose skip rows are in LDS already (issue_chunk_or_skip)
     if (HAS_RES) {
 #pragma unroll
-        for (int k = 0; k < 16; k++)
+        for (int k = SK0; k < 16; k++)
             skip[k] = *reinterpret_cast<const f32x4*>(res + ((size_t)row0 + k * 8 + (elane >> 3)) * (size_t)cout + cout0 + pc * 4);
     }
     // four accumulator elements (couts 8 g + 4 h ..) of every frequency at a time, each read out of its AGPR by an asm statement:
@@ -376,12 +394,18 @@ __global__ void __launch_bounds__(256, 1)
     for (int k = 0; k < 16; k++) {
         const int px = k * 8 + (elane >> 3);
         const f32x4 a = *reinterpret_cast<const f32x4*>(stage + px * 128 + ((pc ^ (px & 7)) << 4));
+        f32x4 sk4 = {0.f, 0.f, 0.f, 0.f};
+        if (HAS_RES) {
+            if (k < SK0)  // piece (k & 3) of the issue (k >> 2): buffer (nch - 2 + (k >> 2)) & 1, slot min(wave * WN_P + (k & 3), 18), this lane's 16 bytes
+                sk4 = *reinterpret_cast<const f32x4*>(smem + WN_LDS_D + ((nch + (k >> 2)) & 1) * WN_DBUF + min(wave * WN_P + (k & 3), 18) * 1024 + elane * 16);
+            else sk4 = skip[k];
+        }
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             // the inverse weight scale is a power of two: the product is exact, the fma rounds once
             float x = __builtin_fmaf(a[j], ds4[j], bias4[j]);
-            if (HAS_RES) x = x + skip[k][j];
+            if (HAS_RES) x = x + sk4[j];
             x = x > 0.0f ? x : 0.0f;
             v[j] = x < WINO_ACT_MAX ? x : WINO_ACT_MAX;  // the next layer's transform relies on it (and counts nothing itself)
         }
