@@ -52,7 +52,35 @@ MFMA_TERMS = {"f16x2": 3, "bf16": 1, "f16": 1, "f32": 1}
 def mfma_terms(dtype: str, kernel: str) -> float:
     """MFMA instructions per algorithmic multiply-add of the tower kernel: the Winograd F(2x2, 3x3) form of the split tower needs
     16 instead of 36 products per 2x2 output tile and input channel, each still three f16 terms."""
-    return MFMA_TERMS[dtype] * (16.0 / 36.0 if kernel == "conv3x3_wino_kernel" else 1.0)
+    return MFMA_TERMS[dtype] * (16.0 / 36.0 if kernel in WINOGRAD_KERNELS else 1.0)
+
+
+WINOGRAD_KERNELS = ("conv3x3_wino_kernel", "conv3x3_wino4_kernel")
+# What the chip's L2s deliver to the CUs when every CU streams rows that its XCD's L2 holds (MI355X_MICROARCH.md, "Indexed rows:
+# gather into LDS": 66-73 GB/s per CU, 16.8-18.8 TB/s chip-wide): the roof of a kernel whose loop is a stream of L2-resident operands
+L2_DELIVERY_TBPS = (16.8, 18.8)
+# (rows, couts) of a workgroup's tile: the bytes a workgroup pulls from L2 per layer are its U block (cout_wg x cin x 16 frequencies x
+# (hi, lo) f16 = 64 B per (cout, cin)) + its input rows (rows_wg x cin x 4 B) + its skip tile (rows_wg x cout_wg x 4 B, every second layer)
+WINOGRAD_WG_TILE = {"conv3x3_wino_kernel": (128, 128), "conv3x3_wino4_kernel": (256, 64)}
+
+
+def delivery_roof(kernel: str, filters: int, rows: int, launch_us: float):
+    """L2 -> CU delivery of a Winograd tower launch, from the kernel's own constants: bytes every workgroup pulls per launch x
+    workgroups / the measured launch duration, against the guide's measured L2 read-out rate."""
+    if kernel not in WINOGRAD_WG_TILE or launch_us <= 0:
+        return None
+    rows_wg, cout_wg = WINOGRAD_WG_TILE[kernel]
+    wgs = -(-rows // rows_wg) * (filters // cout_wg)
+    u, act, skip = cout_wg * filters * 64, rows_wg * filters * 4, rows_wg * cout_wg * 4 // 2
+    per_wg = u + act + skip
+    tbps = per_wg * wgs / (launch_us * 1e-6) / 1e12
+    return {
+        "bytes_per_workgroup": per_wg, "of_which_weights_U": u, "of_which_input_rows": act, "of_which_skip_rows_avg": skip,
+        "workgroups": wgs, "bytes_per_launch": per_wg * wgs, "achieved_TBps": tbps,
+        "roof_TBps": list(L2_DELIVERY_TBPS), "frac_of_roof": [tbps / L2_DELIVERY_TBPS[1], tbps / L2_DELIVERY_TBPS[0]],
+        "roof_source": "MI355X_MICROARCH.md, rows shared through the XCDs' L2s gathered by every CU: 16.8-18.8 TB/s chip-wide",
+        "note": "every byte counted once per workgroup that loads it (U is re-read by every workgroup of its cout group: L2 hits, not HBM)",
+    }
 
 DTYPE_NOTE = {
     "f16x2": "split precision: operands as pairs of f16 values (22 significant bits), three f16 MFMA terms per product, f32 accumulation, "
@@ -698,9 +726,16 @@ def main():
             sustained = dict(tflops=r["sustained"], frac_of_nominal=r["sustained"] / peak,
                              mfma_pipe_frac_of_sustained=mfma_terms(dtype, r["kernel"]) * achieved / r["sustained"],
                              how="cattus_hip_mfma_sustained: back-to-back MFMAs of the tower's kind on every SIMD, no memory traffic, 1 s")
+        deliv = delivery_roof(r["kernel"], d.filters, batch * 64, r["launch_us"]) if d.board == 8 else None
+        # which roof the kernel is under, from the kernel: the 16-frequency Winograd kernel streams 2 MB of U per CU and layer and sits at
+        # ~0.9 of what the L2s deliver -- its MFMA fraction is quoted against a roof it cannot touch, so the line says so
+        bound = "l2_delivery" if deliv and deliv["frac_of_roof"][0] >= 0.75 else "mfma"
         return {
             "kernel": r["kernel"],
-            "bound": "mfma",
+            "bound": bound,
+            "bound_note": "l2_delivery: the loop is a stream of L2-resident operands into the CUs (`delivery`), the matrix pipe waits for it; "
+                          "`frac` stays the MFMA fraction on algorithmic FLOPs for comparison across kernels" if bound != "mfma" else None,
+            "delivery": deliv,
             "achieved": achieved,
             "peak": peak,
             "unit": "TFLOP/s",
@@ -844,9 +879,14 @@ def main():
         lines = [op + [c for c, _ in t] for op, t in zip(opens, ta)]
         agreement = {}
         for dtype in [args.dtype] + ([] if args.no_bf16 or args.dtype == "bf16" else ["bf16"]) + ([] if args.no_f16 or args.dtype == "f16" else ["f16"]):
-            with HipEvaluator(blob, batch_size=games, plane_words=1, dtype=dtype, device=local_rank, flush_us=100) as evx:
+            # created as the timed evaluator of that dtype is (same max_batch => same tower form, same kernel): the line pairs a kernel's
+            # throughput with THAT kernel's search accuracy (the leaf server runs the 16 threads' leaves as partial batches of it)
+            with HipEvaluator(blob, batch_size=batch, plane_words=1, dtype=dtype, device=local_rank, flush_us=100) as evx:
                 tb = ag.run_traces("chess", cfg, sp.Net.hip_batched(evx), lines, 2, args.agreement_plies)
+                kernel = evx.tower_kernel()
             agreement[dtype] = ag.compare_traces(ta, tb)
+            agreement[dtype]["tower_kernel"] = kernel
+            agreement[dtype]["max_batch"] = batch
         agreement.update(games=games, sims_per_move=800, searched_plies_per_game=args.agreement_plies, seconds=time.perf_counter() - t0,
                          note="f32 plays; each tower searches the same positions (teacher-forced, trees carried over); greedy move choice, noise "
                               "off. tests/test_search_parity_gpu.py runs 16 plies per game and bounds these numbers; larger samples: "

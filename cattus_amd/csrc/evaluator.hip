@@ -26,6 +26,7 @@
 #include <dlfcn.h>
 
 #include "../../include/cattus_hip.h"
+#include "../../include/cattus_hip_diag.h"
 #include "kernels.h"
 
 // Kernel arguments in device memory: by default the HIP runtime keeps the kernel-argument ring in host memory and the
@@ -267,6 +268,7 @@ struct cattus_eval {
     // bf16 networks with <= 64 filters: the whole tower in one launch, activations resident in LDS
     // (tower64_lds_kernel; CATTUS_TOWER64=0 selects the per-layer launches, for A/B runs and the equality test)
     bool tower64 = false;
+    bool resident_tower = true;  // diagnostic switch CATTUS_TOWER64=0: per-layer launches instead (A/B runs, the equality tests)
     DevBuf t64_layers;
     // f16x2 networks with <= 64 filters: the same, in split precision (tower64_split_kernel; weights from the register ring)
     bool tower64s = false;
@@ -612,8 +614,7 @@ int build(cattus_eval* e, const float* p) {
     }
 
     if (e->tuned && e->act == Act::BF16 && FP == 64 && e->cpad0 == 64) {
-        const char* sw = getenv("CATTUS_TOWER64");
-        e->tower64 = !(sw && sw[0] == '0');
+        e->tower64 = e->resident_tower;
         std::vector<Tower64Layer> tl;
         tl.push_back(Tower64Layer{e->stem.w.p, e->stem.b.as<float>(), 0, 0});
         for (uint32_t i = 0; i < d.blocks; i++) {
@@ -624,8 +625,7 @@ int build(cattus_eval* e, const float* p) {
     }
 
     if (e->tuned && e->act == Act::F16S && FP == 64 && e->cpad0 == 32 && e->split_wfrag && 1 + 2 * d.blocks <= (uint32_t)T64S_MAX_LAYERS) {
-        const char* sw = getenv("CATTUS_TOWER64");
-        e->tower64s = !(sw && sw[0] == '0');
+        e->tower64s = e->resident_tower;
         std::vector<Tower64SplitLayer> tl;
         tl.push_back(Tower64SplitLayer{e->stem.wf.p, e->stem.b.as<float>(), 0, 1});
         for (uint32_t i = 0; i < d.blocks; i++) {
@@ -966,11 +966,55 @@ CATTUS_API const char* cattus_hip_tower_kernel(const cattus_eval* e) {
     return "conv3x3_mfma_v2_kernel";
 }
 
-CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattus_eval_config* cfg, cattus_eval** out) {
+namespace {
+
+// Diagnostic switches of cattus_hip_create_diag (include/cattus_hip_diag.h): "KEY=VALUE;KEY=VALUE".  cattus_hip_create passes none,
+// and the library reads no A/B switch from the environment: what a host links is one code path per configuration.
+struct Switches {
+    std::map<std::string, std::string> kv;
+    int parse(const char* text) {
+        if (!text) return CATTUS_OK;
+        static const char* const known[] = {"CATTUS_CONV_CB", "CATTUS_CONV_PBW", "CATTUS_FUSED_STEM", "CATTUS_T64_CH", "CATTUS_T64_LS", "CATTUS_SPLIT_W",
+                                            "CATTUS_T64S_HEADS", "CATTUS_T64S_SHAPE", "CATTUS_TOWER64", "CATTUS_FORCE_GENERIC", "CATTUS_WINO_INPLACE",
+                                            "CATTUS_ARENA", "CATTUS_WINO_KERNEL"};
+        const std::string s(text);
+        size_t at = 0;
+        while (at < s.size()) {
+            size_t end = s.find(';', at);
+            if (end == std::string::npos) end = s.size();
+            const std::string item = s.substr(at, end - at);
+            at = end + 1;
+            if (item.empty()) continue;
+            const size_t eq = item.find('=');
+            if (eq == std::string::npos || eq == 0) return fail(CATTUS_E_INVALID, "diagnostic switch '%s' is not KEY=VALUE", item.c_str());
+            const std::string key = item.substr(0, eq);
+            bool ok = false;
+            for (const char* k : known) ok = ok || key == k;
+            if (!ok) return fail(CATTUS_E_INVALID, "unknown diagnostic switch '%s'", key.c_str());
+            kv[key] = item.substr(eq + 1);
+        }
+        return CATTUS_OK;
+    }
+    const char* get(const char* key) const {
+        auto it = kv.find(key);
+        return it == kv.end() ? nullptr : it->second.c_str();
+    }
+};
+
+int create_impl(const void* weights, size_t nbytes, const cattus_eval_config* cfg_in, const char* switches, cattus_eval** out) {
     if (!out) return fail(CATTUS_E_INVALID, "out is NULL");
     *out = nullptr;
-    if (!weights || !cfg) return fail(CATTUS_E_INVALID, "weights/cfg is NULL");
-    if (cfg->struct_size != sizeof(cattus_eval_config)) return fail(CATTUS_E_INVALID, "cfg.struct_size mismatch");
+    if (!weights || !cfg_in) return fail(CATTUS_E_INVALID, "weights/cfg is NULL");
+    // struct_size versions the configuration: 24 bytes = the fields up to flush_us (tower_form = AUTO), 28 = with tower_form
+    cattus_eval_config cfg_copy{};
+    if (cfg_in->struct_size == offsetof(cattus_eval_config, tower_form)) memcpy(&cfg_copy, cfg_in, offsetof(cattus_eval_config, tower_form));
+    else if (cfg_in->struct_size == sizeof(cattus_eval_config)) cfg_copy = *cfg_in;
+    else return fail(CATTUS_E_INVALID, "cfg.struct_size mismatch");
+    cfg_copy.struct_size = sizeof(cattus_eval_config);
+    const cattus_eval_config* cfg = &cfg_copy;
+    if (cfg->tower_form > CATTUS_TOWER_WINOGRAD) return fail(CATTUS_E_INVALID, "unknown tower_form %u", cfg->tower_form);
+    Switches sw;
+    if (int src = sw.parse(switches)) return src;
     if (nbytes < HEADER_BYTES || memcmp(weights, "CATTUSW1", 8) != 0) return fail(CATTUS_E_INVALID, "not a cattus weight blob");
     uint32_t h[9];
     memcpy(h, (const char*)weights + 8, sizeof h);
@@ -1016,16 +1060,16 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
                                             : "HIP_FORCE_DEV_KERNARG is not 1: kernel arguments travel over the host link (about +8 % per batch); "
                                               "export HIP_FORCE_DEV_KERNARG=1 before the process initialises HIP";
     }
-    const char* wait_mode = getenv("CATTUS_HIP_WAIT");
-    const char* conv_cb_env = getenv("CATTUS_CONV_CB");
-    const char* conv_pbw_env = getenv("CATTUS_CONV_PBW");
-    const char* fused_stem_env = getenv("CATTUS_FUSED_STEM");
-    const char* t64_ch_env = getenv("CATTUS_T64_CH");
-    const char* t64_ls_env = getenv("CATTUS_T64_LS");
-    const char* split_w_env = getenv("CATTUS_SPLIT_W");
-    const char* t64s_heads_env = getenv("CATTUS_T64S_HEADS");
-    const char* winograd_env = getenv("CATTUS_WINOGRAD");
-    const char* t64s_d_env = getenv("CATTUS_T64S_SHAPE");
+    const char* wait_mode = getenv("CATTUS_HIP_WAIT");  // operational, not A/B: how the host thread waits for a batch
+    const char* conv_cb_env = sw.get("CATTUS_CONV_CB");
+    const char* conv_pbw_env = sw.get("CATTUS_CONV_PBW");
+    const char* fused_stem_env = sw.get("CATTUS_FUSED_STEM");
+    const char* t64_ch_env = sw.get("CATTUS_T64_CH");
+    const char* t64_ls_env = sw.get("CATTUS_T64_LS");
+    const char* split_w_env = sw.get("CATTUS_SPLIT_W");
+    const char* t64s_heads_env = sw.get("CATTUS_T64S_HEADS");
+    const char* t64s_d_env = sw.get("CATTUS_T64S_SHAPE");
+    const char* tower64_env = sw.get("CATTUS_TOWER64");
 
     std::unique_ptr<cattus_eval> e(new (std::nothrow) cattus_eval);
     if (!e) return fail(CATTUS_E_NOMEM, "out of memory");
@@ -1038,7 +1082,10 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->t64_force_ch = t64_ch_env ? atoi(t64_ch_env) : 0;
     e->t64_layer_steps = !(t64_ls_env && atoi(t64_ls_env) == 0);
     e->split_wfrag = !(split_w_env && split_w_env[0] == '0');
-    e->winograd = winograd_env ? winograd_env[0] == '1' : cfg->max_batch >= 192;
+    // the tower's form is part of the configuration (a leaf's bits must not depend on the batch it came in, so never per batch):
+    // AUTO = Winograd for max_batch >= 192 where the shape allows it; WINOGRAD on a shape it does not cover is refused below
+    e->winograd = cfg->tower_form == CATTUS_TOWER_WINOGRAD || (cfg->tower_form == CATTUS_TOWER_AUTO && cfg->max_batch >= 192);
+    e->resident_tower = !(tower64_env && tower64_env[0] == '0');
     e->t64s_fuse_heads = !(t64s_heads_env && t64s_heads_env[0] == '0');
     e->t64s_depth = t64s_d_env ? atoi(t64s_d_env) : 0;
     if (e->t64s_depth != 1 && e->t64s_depth != 2 && e->t64s_depth != 9) e->t64s_depth = 0;
@@ -1048,7 +1095,7 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     // The MFMA tower covers every board up to 11x11 and any filter count (channels are padded to 64 with zeros);
     // the two 1x1 head convs share one 32-row MFMA tile.  Wider heads take the generic f32 path (one thread
     // per output, same arithmetic order), which otherwise serves as a checker only (CATTUS_FORCE_GENERIC=1).
-    const char* force_generic = getenv("CATTUS_FORCE_GENERIC");
+    const char* force_generic = sw.get("CATTUS_FORCE_GENERIC");
     e->simple = simple;
     e->tuned = !simple && d.vhc + d.phc <= 32 && !(force_generic && force_generic[0] == '1');
     e->act = simple ? Act::F32
@@ -1073,9 +1120,12 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     e->fpad = e->tuned ? (d.filters + COUT_PER_WG - 1) / COUT_PER_WG * COUT_PER_WG : d.filters;
     const uint32_t bpw = e->tuned ? ROWS_PER_WG / e->slots : 1;
     e->bpad = (cfg->max_batch + bpw - 1) / bpw * bpw;
-    const char* inplace_env = getenv("CATTUS_WINO_INPLACE");
+    const char* inplace_env = sw.get("CATTUS_WINO_INPLACE");
     e->wino_inplace = !(inplace_env && inplace_env[0] == '0');
-    const char* arena_env = getenv("CATTUS_ARENA");  // 0: every buffer its own allocation (A/B runs)
+    const char* arena_env = sw.get("CATTUS_ARENA");  // 0: every buffer its own allocation (A/B runs)
+    if (cfg->tower_form == CATTUS_TOWER_WINOGRAD &&
+        !(e->tuned && e->act == Act::F16S && d.blocks > 0 && wino_supported(e->bpad, e->fpad, e->fpad, d.board)))
+        return fail(CATTUS_E_UNSUPPORTED, "tower_form WINOGRAD needs dtype f16x2, an 8x8 board, at least one residual block and a multiple of 128 filters");
     if (e->tuned && e->act == Act::F16S && e->winograd && d.blocks > 0 && wino_supported(e->bpad, e->fpad, e->fpad, d.board) &&
         !(arena_env && arena_env[0] == '0')) {
         // the Winograd tower's hot set in one block: U of every layer, then the lanes' activation buffers (DevArena)
@@ -1097,6 +1147,16 @@ CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattu
     for (auto& t : e->servers) t = std::thread(server_loop, e.get());
     *out = e.release();
     return CATTUS_OK;
+}
+
+}  // namespace
+
+CATTUS_API int cattus_hip_create(const void* weights, size_t nbytes, const cattus_eval_config* cfg, cattus_eval** out) {
+    return create_impl(weights, nbytes, cfg, nullptr, out);
+}
+
+CATTUS_API int cattus_hip_create_diag(const void* weights, size_t nbytes, const cattus_eval_config* cfg, const char* switches, cattus_eval** out) {
+    return create_impl(weights, nbytes, cfg, switches, out);
 }
 
 CATTUS_API void cattus_hip_destroy(cattus_eval* e) { delete e; }

@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "cattus_hip_version",
     "cattus_hip_runtime_note",
     "cattus_hip_tower_kernel",
+    "cattus_hip_create_diag",  # include/cattus_hip_diag.h
 ]
 
 
@@ -68,7 +69,16 @@ class EvalConfig(C.Structure):
         ("plane_words", C.c_uint32),
         ("dtype", C.c_uint32),
         ("flush_us", C.c_uint32),
+        ("tower_form", C.c_uint32),
     ]
+
+
+TOWER_FORMS = {"auto": 0, "direct": 1, "winograd": 2}  # cattus_tower_form
+# Diagnostic switches (include/cattus_hip_diag.h).  The library reads none of them from the environment; this binding -- the
+# harness of the tests and the timing scripts -- forwards the ones it finds there through cattus_hip_create_diag, so that
+# `CATTUS_TOWER64=0 python scripts/...` and monkeypatch.setenv keep working.  CATTUS_WINOGRAD=0/1 (rounds 3-4) maps to tower_form.
+DIAG_SWITCHES = ("CATTUS_CONV_CB", "CATTUS_CONV_PBW", "CATTUS_FUSED_STEM", "CATTUS_T64_CH", "CATTUS_T64_LS", "CATTUS_SPLIT_W", "CATTUS_T64S_HEADS",
+                 "CATTUS_T64S_SHAPE", "CATTUS_TOWER64", "CATTUS_FORCE_GENERIC", "CATTUS_WINO_INPLACE", "CATTUS_ARENA", "CATTUS_WINO_KERNEL")
 
 
 class Stats(C.Structure):
@@ -103,6 +113,7 @@ def load_library():
     u64p, f32p = C.POINTER(C.c_uint64), C.POINTER(C.c_float)
     vp = C.c_void_p
     L.cattus_hip_create.argtypes = [vp, C.c_size_t, C.POINTER(EvalConfig), C.POINTER(vp)]
+    L.cattus_hip_create_diag.argtypes = [vp, C.c_size_t, C.POINTER(EvalConfig), C.c_char_p, C.POINTER(vp)]
     L.cattus_hip_destroy.argtypes = [vp]
     L.cattus_hip_destroy.restype = None
     L.cattus_hip_desc.argtypes = [vp, C.POINTER(NetDescC)]
@@ -180,17 +191,34 @@ class HipEvaluator:
         dtype: str = "bf16",
         device: int = 0,
         flush_us: int = 200,
+        tower_form: str | None = None,
+        switches: dict | None = None,
     ):
+        """tower_form: "auto" | "direct" | "winograd" (cattus_tower_form; None = "auto", or what CATTUS_WINOGRAD=0/1 in the
+        environment says).  switches: diagnostic switches for cattus_hip_create_diag (None = the CATTUS_* ones found in the
+        environment, {} = none)."""
         self.desc: NetDesc = parse_header(blob)
         self.batch_size = int(batch_size)
         self.plane_words = int(plane_words)
         self.dtype = dtype
         self.device = device
         self._lib = load_library()
-        cfg = EvalConfig(C.sizeof(EvalConfig), device, self.batch_size, self.plane_words, _DTYPES[dtype], flush_us)
+        if tower_form is None:
+            legacy = os.environ.get("CATTUS_WINOGRAD")
+            tower_form = "auto" if not legacy else ("winograd" if legacy[0] == "1" else "direct")
+            if tower_form == "winograd" and not (dtype == "f16x2" and self.desc.board == 8 and self.desc.blocks > 0 and self.desc.filters % 128 == 0):
+                tower_form = "auto"  # the environment form was a wish ("where the shape allows it"); the config field is a demand
+        if switches is None:
+            switches = {k: os.environ[k] for k in DIAG_SWITCHES if k in os.environ}
+        self.tower_form = tower_form
+        cfg = EvalConfig(C.sizeof(EvalConfig), device, self.batch_size, self.plane_words, _DTYPES[dtype], flush_us, TOWER_FORMS[tower_form])
         h = C.c_void_p()
         buf = C.create_string_buffer(blob, len(blob))
-        _check(self._lib.cattus_hip_create(buf, len(blob), C.byref(cfg), C.byref(h)))
+        if switches:
+            text = ";".join(f"{k}={v}" for k, v in switches.items()).encode()
+            _check(self._lib.cattus_hip_create_diag(buf, len(blob), C.byref(cfg), text, C.byref(h)))
+        else:
+            _check(self._lib.cattus_hip_create(buf, len(blob), C.byref(cfg), C.byref(h)))
         self._h = h
 
     # -- lifetime ---------------------------------------------------------------------------

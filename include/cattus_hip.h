@@ -51,15 +51,24 @@ typedef enum cattus_dtype {
     CATTUS_DTYPE_F16 = 3,
 } cattus_dtype;
 
+/* Form of the f16x2 conv tower on 8x8 boards with a multiple of 128 filters.  The two forms agree to < 2e-6 per logit but not
+ * bit for bit, and a leaf's bits must not depend on the batch it came in: the form is fixed per evaluator, here. */
+typedef enum cattus_tower_form {
+    CATTUS_TOWER_AUTO = 0,     /* Winograd where the shape allows it and max_batch >= 192 (full batches), else direct */
+    CATTUS_TOWER_DIRECT = 1,   /* direct 3x3 (conv3x3_splitw_kernel): the faster form below ~192 leaves per batch */
+    CATTUS_TOWER_WINOGRAD = 2, /* Winograd F(2x2,3x3) whatever max_batch is; CATTUS_E_UNSUPPORTED where no such kernel exists */
+} cattus_tower_form;
+
 /* Replaces the reference's InferenceConfig + batch_size (engine/src/net/model.rs:17-25,
  * training/self-play/src/self_play_cmd.rs:41-44). */
 typedef struct cattus_eval_config {
-    uint32_t struct_size; /* sizeof(cattus_eval_config) */
+    uint32_t struct_size; /* sizeof(cattus_eval_config); 24 (the fields up to flush_us, tower_form = AUTO) is accepted too */
     int32_t device;       /* HIP device ordinal */
     uint32_t max_batch;   /* model.batch_size: largest n accepted by eval / batch the server fills */
     uint32_t plane_words; /* u64 words per bitboard plane: chess 1, ttt 1, hex 2 (u128 as lo,hi) */
     uint32_t dtype;       /* cattus_dtype */
     uint32_t flush_us;    /* partial-batch deadline of the leaf server (reference: 20 ms, net/mod.rs:96) */
+    uint32_t tower_form;  /* cattus_tower_form; ignored by every dtype but f16x2 */
 } cattus_eval_config;
 
 typedef struct cattus_stats {
@@ -81,7 +90,10 @@ typedef struct cattus_net_desc {
     uint32_t planes, board, moves, blocks, filters, vhc, phc, fc_hidden;
 } cattus_net_desc;
 
-/* Model::new (model.rs:61): parse the weight blob (copied), fold BatchNorm, upload. */
+/* Model::new (model.rs:61): parse the weight blob (copied), fold BatchNorm, upload.  Everything that selects a code path is in
+ * `cfg`; the library reads two operational environment variables and no other: CATTUS_HIP_WAIT=block (the host thread sleeps
+ * on an event instead of spinning while a batch runs) and CATTUS_ROCTX=1 (ROCTx ranges around every batch).  The A/B switches
+ * of the tests and timing scripts go through cattus_hip_create_diag (cattus_hip_diag.h), never through the environment. */
 int cattus_hip_create(const void* weights, size_t nbytes, const cattus_eval_config* cfg, cattus_eval** out);
 void cattus_hip_destroy(cattus_eval* e);
 int cattus_hip_desc(const cattus_eval* e, cattus_net_desc* out);

@@ -33,6 +33,8 @@ struct CattusEvalConfig {
     plane_words: u32,
     dtype: u32,
     flush_us: u32,
+    /// cattus_tower_form: 0 = auto (Winograd form of the f16x2 tower for batch_size >= 192), 1 = direct, 2 = Winograd
+    tower_form: u32,
 }
 
 #[repr(C)]
@@ -94,6 +96,7 @@ impl HipModel {
             dtype: dtype as u32,
             // partial batches run after 200 us (the reference's Batcher waits 20 ms: net/mod.rs:96)
             flush_us: 200,
+            tower_form: 0,
         };
         let mut h = std::ptr::null_mut();
         check(unsafe { cattus_hip_create(blob.as_ptr().cast(), blob.len(), &cfg, &mut h) });

@@ -8,7 +8,8 @@ times (BASELINE config 3: 800 simulations per move):
     count) -- at a size the oracle finishes in seconds -- and, for the full-size run below, leaf for leaf
     on a sample of the positions the games went through.
  2. f32 evaluator, 800 sims/move, 16 games x 16 searched plies: the reference-precision search.
- 3. the split-precision evaluator (f16x2, the product default) and the bf16 evaluator searching the SAME positions
+ 3. the split-precision evaluator (f16x2, the product default) -- in its direct form AND in the Winograd form the headline
+    of bench.py is timed on (an evaluator of max_batch 256) -- and the bf16 evaluator searching the SAME positions
     (teacher-forced, cattus_amd/agreement.py): chosen-move agreement and L1 distance of the root visit distributions
     are reported and bounded (floors stated below and in DESIGN.md section 4).
 
@@ -39,6 +40,7 @@ BF16_VISIT_L1_MAX = 0.09
 # at most 2 chosen moves may differ (>= 99.2 %), see profiles/r03_search_agreement.json for 2,048 and 3,888 searches
 F16X2_MOVE_AGREEMENT_MIN = 0.992
 F16X2_VISIT_L1_MEAN_MAX = 4e-4
+WINOGRAD_KERNELS = ("conv3x3_wino_kernel", "conv3x3_wino4_kernel")  # the Winograd form's kernels (same bits)
 
 
 def _positions_of(lines, upto):
@@ -85,14 +87,31 @@ def test_chess_20x256_search_f32_equals_oracle_and_bf16_agreement_is_bounded():
 
     # ---- 3a. the split-precision tower on the same positions
     with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="f16x2", flush_us=100) as evs:
+        assert evs.tower_kernel() == "conv3x3_splitw_kernel"
         ts = ag.run_traces("chess", cfg, sp.Net.hip_batched(evs), lines, 2, plies)
         assert ts == ag.run_traces("chess", cfg, sp.Net.hip_batched(evs), lines, 2, plies)  # reproducible
         ps, vs = evs.eval(sample[:games])
     res_s = ag.compare_traces(ta, ts)
-    res_s.update(dtype="f16x2", leaf_max_abs_dlogit=float(np.abs(ps - p_or).max()), leaf_max_abs_dvalue=float(np.abs(vs - v_or).max()))
+    res_s.update(dtype="f16x2", tower_kernel="conv3x3_splitw_kernel", leaf_max_abs_dlogit=float(np.abs(ps - p_or).max()), leaf_max_abs_dvalue=float(np.abs(vs - v_or).max()))
     print("f16x2 vs f32 search agreement:", json.dumps(res_s))
     assert res_s["move_agreement"] >= F16X2_MOVE_AGREEMENT_MIN, res_s
     assert res_s["visit_l1_mean"] <= F16X2_VISIT_L1_MEAN_MAX, res_s
+
+    # ---- 3a'. the same tower in the form the HEADLINE runs: an evaluator created as bench.py creates its own (max_batch 256, tower_form
+    # AUTO -> Winograd F(2x2,3x3), conv3x3_wino_kernel) searching the same positions through the same leaf server.  Same floors as the
+    # direct form; measured on 2,048 searches (profiles/r04_search_agreement_winograd.jsonl): every move and every visit count equal.
+    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2", flush_us=100) as evw:
+        assert evw.tower_kernel() in WINOGRAD_KERNELS, evw.tower_kernel()
+        tw = ag.run_traces("chess", cfg, sp.Net.hip_batched(evw), lines, 2, plies)
+        assert tw == ag.run_traces("chess", cfg, sp.Net.hip_batched(evw), lines, 2, plies)  # reproducible, whatever batch a leaf came in
+        pw, vw = evw.eval(sample[:games])
+        kernel_w = evw.tower_kernel()
+    res_w = ag.compare_traces(ta, tw)
+    res_w.update(dtype="f16x2", tower_kernel=kernel_w, leaf_max_abs_dlogit=float(np.abs(pw - p_or).max()), leaf_max_abs_dvalue=float(np.abs(vw - v_or).max()))
+    print("f16x2 (Winograd form) vs f32 search agreement:", json.dumps(res_w))
+    assert res_w["plies"] >= games * plies - 8
+    assert res_w["move_agreement"] >= F16X2_MOVE_AGREEMENT_MIN, res_w
+    assert res_w["visit_l1_mean"] <= F16X2_VISIT_L1_MEAN_MAX, res_w
 
     # ---- 3b. bf16 on the same positions
     with HipEvaluator(blob, batch_size=games, plane_words=1, dtype="bf16", flush_us=100) as ev16:
@@ -106,7 +125,7 @@ def test_chess_20x256_search_f32_equals_oracle_and_bf16_agreement_is_bounded():
                leaf_argmax_agreement=float((p16.argmax(1) == p_or.argmax(1)).mean()))
     out = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent)) / "gpurun_out"
     out.mkdir(exist_ok=True)
-    (out / "search_agreement.json").write_text(json.dumps({"bf16": res, "f16x2": res_s}, indent=1))
+    (out / "search_agreement.json").write_text(json.dumps({"bf16": res, "f16x2": res_s, "f16x2_winograd": res_w}, indent=1))
     print("bf16 vs f32 search agreement:", json.dumps(res))
     assert res["plies"] >= games * plies - 8
     assert res["move_agreement"] >= BF16_MOVE_AGREEMENT_MIN, res
