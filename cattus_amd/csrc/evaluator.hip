@@ -282,6 +282,9 @@ struct cattus_eval {
     // in: for max_batch >= 192 (below that the direct kernels' small tiles win: 14 against 33 us per launch at 64 leaves of chess
     // 20x256, 42.8 against 37.5 at 256); CATTUS_WINOGRAD=0 / 1 forbids / forces it.
     bool winograd = false;
+    // which Winograd kernel: the 4-frequencies x 2x2-blocks one (kernels_wino4.hip) wherever it covers the shape, else the
+    // 16-frequencies one (kernels_wino.hip); same bits; diagnostic switch CATTUS_WINO_KERNEL=k16|k4
+    bool wino_k4 = true;
     bool wino_inplace = true;      // CATTUS_WINO_INPLACE=0: a third activation buffer for the blocks' outputs (A/B runs)
     bool split_wfrag = true;       // CATTUS_SPLIT_W=0: f16x2 weights through the LDS ring (conv3x3_split_kernel) instead of the register ring
     // tile-forcing switches (CATTUS_CONV_CB, CATTUS_CONV_PBW: A/B runs, the tile-equality tests) and the f16 towers' saturation
@@ -342,6 +345,11 @@ size_t blob_floats(const cattus_net_desc& d) {
     return n;
 }
 
+// The Winograd kernel this evaluator would run a cin -> cout layer on covers that shape.
+bool wino_shape_ok(const cattus_eval* e, uint32_t cin, uint32_t cout) {
+    return e->wino_k4 ? wino4_supported(e->bpad, cin, cout, e->d.board) : wino_supported(e->bpad, cin, cout, e->d.board);
+}
+
 // Upload one folded 3x3 layer in the layout of the selected tower.  On the tuned path output channels are
 // padded to `cout_pad` and input channels to the device layout of the producing layer (`cin_pad`, a multiple of
 // one 128-byte row) with zero weights and zero bias: a padded channel computes relu(0) = 0, and as an input it
@@ -383,7 +391,7 @@ int upload_conv(cattus_eval* e, ConvLayer& L, const Folded& f, uint32_t cout, ui
                 }
         }
         if ((rc = L.b.upload(b.data(), b.size() * sizeof(float)))) return rc;
-        if (e->winograd && &L != &e->stem && wino_supported(e->bpad, cin_pad, cout_pad, e->d.board)) {
+        if (e->winograd && &L != &e->stem && wino_shape_ok(e, cin_pad, cout_pad)) {
             // Winograd F(2x2, 3x3) form: U = G g G^T per (cout, cin) in float64, one power-of-two scale per output channel over
             // all 16 frequencies (largest |U 2^s| in [2^10, 2^11)), split into (hi, lo), in the kernel's fragment order
             static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -747,7 +755,8 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             const bool wino = d.blocks > 0 && e->c1[0]->wu.p != nullptr;
             auto conv = [&](const ConvLayer& c, const void* in, const void* res, void* out, int lflags) {
                 hipEvent_t s0 = ev(false), s1 = ev(true);
-                if (wino) launch_conv3x3_wino((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
+                if (wino && e->wino_k4) launch_conv3x3_wino4((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
+                else if (wino) launch_conv3x3_wino((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
                 else launch_conv3x3_mfma(e->act, in, wptr(c), c.b.as<float>(), res, out, nb, FP, FP, S, st, s0, s1, nullptr, wflag | lflags, e->conv_opts);
             };
             for (uint32_t i = 0; i < d.blocks; i++) {
@@ -962,7 +971,7 @@ CATTUS_API const char* cattus_hip_tower_kernel(const cattus_eval* e) {
     if (!e->tuned) return "conv3x3_generic_kernel";
     if (e->tower64) return "tower64_lds_kernel";
     if (e->tower64s) return "tower64_split_kernel";
-    if (e->act == Act::F16S) return e->d.blocks > 0 && e->c1[0]->wu.p ? "conv3x3_wino_kernel" : e->split_wfrag ? "conv3x3_splitw_kernel" : "conv3x3_split_kernel";
+    if (e->act == Act::F16S) return e->d.blocks > 0 && e->c1[0]->wu.p ? (e->wino_k4 ? "conv3x3_wino4_kernel" : "conv3x3_wino_kernel") : e->split_wfrag ? "conv3x3_splitw_kernel" : "conv3x3_split_kernel";
     return "conv3x3_mfma_v2_kernel";
 }
 
@@ -1123,10 +1132,15 @@ int create_impl(const void* weights, size_t nbytes, const cattus_eval_config* cf
     const char* inplace_env = sw.get("CATTUS_WINO_INPLACE");
     e->wino_inplace = !(inplace_env && inplace_env[0] == '0');
     const char* arena_env = sw.get("CATTUS_ARENA");  // 0: every buffer its own allocation (A/B runs)
-    if (cfg->tower_form == CATTUS_TOWER_WINOGRAD &&
-        !(e->tuned && e->act == Act::F16S && d.blocks > 0 && wino_supported(e->bpad, e->fpad, e->fpad, d.board)))
-        return fail(CATTUS_E_UNSUPPORTED, "tower_form WINOGRAD needs dtype f16x2, an 8x8 board, at least one residual block and a multiple of 128 filters");
-    if (e->tuned && e->act == Act::F16S && e->winograd && d.blocks > 0 && wino_supported(e->bpad, e->fpad, e->fpad, d.board) &&
+    {
+        // the 4-frequency kernel wherever it covers the layer shape (filters a multiple of 64), else the 16-frequency one (128)
+        const char* wk = sw.get("CATTUS_WINO_KERNEL");
+        if (wk && strcmp(wk, "k16") != 0 && strcmp(wk, "k4") != 0) return fail(CATTUS_E_INVALID, "CATTUS_WINO_KERNEL is k16 or k4");
+        e->wino_k4 = wk ? strcmp(wk, "k4") == 0 : wino4_supported(e->bpad, e->fpad, e->fpad, d.board);
+    }
+    if (cfg->tower_form == CATTUS_TOWER_WINOGRAD && !(e->tuned && e->act == Act::F16S && d.blocks > 0 && wino_shape_ok(e.get(), e->fpad, e->fpad)))
+        return fail(CATTUS_E_UNSUPPORTED, "tower_form WINOGRAD needs dtype f16x2, an 8x8 board, at least one residual block and a multiple of 64 filters");
+    if (e->tuned && e->act == Act::F16S && e->winograd && d.blocks > 0 && wino_shape_ok(e.get(), e->fpad, e->fpad) &&
         !(arena_env && arena_env[0] == '0')) {
         // the Winograd tower's hot set in one block: U of every layer, then the lanes' activation buffers (DevArena)
         auto page = [](size_t b) { return (b + 4095) & ~(size_t)4095; };

@@ -98,6 +98,14 @@ void launch_conv3x3_wino(const float* in, const void* wu, const float* bias, con
                          uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat);
 hipError_t prepare_wino();  // its dynamic-LDS opt-in; called by prepare_device()
 
+// ---- K1w4: the same layer with 4 frequencies x (2 tile blocks x 2 cout blocks) per wave (kernels_wino4.hip) ----
+// Same arguments, same U buffer, same bits as launch_conv3x3_wino; workgroup = 4 boards x 64 couts (bpad % 4 == 0, cout % 64 == 0):
+// half of K1w's U bytes per CU, the transformed input made in registers.  The evaluator prefers it wherever it is supported.
+bool wino4_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S);
+void launch_conv3x3_wino4(const float* in, const void* wu, const float* bias, const float* res, float* out, uint32_t bpad, uint32_t cin,
+                          uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat);
+hipError_t prepare_wino4();
+
 // Diagnostic: one launch of nothing but back-to-back MFMAs of the tower's kind (F16S: f16, BF16, F32: 32x32x2 f32), four
 // waves on each of `cus` workgroups, iters x 4 MFMAs per wave; `out` holds cus * 256 floats.  Returns the launch's FLOPs.
 double launch_mfma_sustain(Act act, int cus, int iters, float* out, hipStream_t st);

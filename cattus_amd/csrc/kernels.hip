@@ -2073,6 +2073,8 @@ hipError_t prepare_device() {
     if (err == hipSuccess) err = e3;
     const hipError_t e4 = prepare_wino();
     if (err == hipSuccess) err = e4;
+    const hipError_t e5 = prepare_wino4();
+    if (err == hipSuccess) err = e5;
     return err;
 }
 

@@ -1,0 +1,397 @@
+// gfx950 kernels of the Cattus leaf evaluator, part 4: the Winograd F(2x2, 3x3) split conv with a 2 x 2 block per frequency (K1w4).
+//
+// conv3x3_wino_kernel (kernels_wino.hip) gives a wave the 16 frequencies of ONE (32 tiles x 32 couts) block: all 256 accumulator
+// registers, every operand fragment feeds one accumulator, and the U stream -- 2 MB per CU and layer -- runs at what the XCDs' L2s
+// deliver (bench.py: roofline.delivery 0.97-1.1 of the guide's 16.8-18.8 TB/s) while the matrix pipe is 0.3 busy.  This kernel
+// spends the same 256 registers on 4 frequencies x (2 tile blocks x 2 cout blocks): a U fragment feeds two tile blocks, and the
+// transformed input never exists in memory at all --
+//   workgroup = 4 waves = 4 boards (64 tiles, 256 pixel rows) x 64 couts; wave q owns frequency ROW q (f = 4 q + l, l = 0..3) of
+//       both tile blocks (boards 0-1, 2-3) and both cout blocks: 16 accumulators acc[l][tb][cb]
+//   U: the same buffer and fragment order as K1w ([cout / 32][k-step x 16 + f][hi | lo][lane][8 f16]); a wave streams ITS four
+//       frequencies of its two cout blocks: 1 MB per CU and layer, half of K1w's, each byte of it loaded by exactly one wave
+//   V = B^T d B IN REGISTERS, in MFMA operand layout: lane (tile n, k-half h) needs row q of B^T d B for channels 8h..8h+7 of
+//       its own tile -- two patch rows (B^T row q combines two), four columns -- read straight from the activation chunk in LDS
+//       (ds_read_b128, 4 channels), combined in f32 (the order of K1w: rows first, then columns), split into (hi, lo) and
+//       written into the registers the MFMAs read.  No V image, no V write, no V fragment read, no barrier for V; the four waves
+//       do the same number of additions in total as K1w's shared transform (each does one row of the four).
+//   d: 32-channel chunks of the 256 pixel rows by LDS-DMA, two images per buffer (one per tile block, K1w's layout: pixel pitch
+//       144 B, 64 B per board row, zero area for off-board patch pixels, and the second board one 16-B piece to the right: with
+//       32 DIFFERENT tiles per half wave that is what keeps the four 16-lane groups of a ds_read_b128 on 16 different bank slots)
+//   per k-step (16 channels) a wave issues 48 MFMAs (as K1w), 16 global_load_dwordx4 (K1w: 32) and 32 ds_read_b128 (K1w: 32 of
+//       fragments + 16 b64 of patch + 16 writes), between which sit ~224 VALU instructions of transform (K1w: ~210)
+//   stage order of a k-step: (tb0,l0) (tb0,l1) (tb1,l0) (tb1,l1) (tb0,l2) (tb0,l3) (tb1,l2) (tb1,l3): a U stage (4 loads, 16
+//       registers) lives for three stages and its ring slot has five stages (960 MFMA cycles) to refill -- a ring of ONE k-step
+//       (64 registers); V of k-step s+1 is made in 24-gap phases (tb0: stages 2-5 of k-step s, tb1: stages 6-7 and the next 0-1)
+//       into the l = 0,1 registers as they fall free and into the other of two l = 2,3 sets
+//   epilogue: Z[q][c'] = row q of M A per lane, exchanged through LDS (128 KB, XOR-swizzled), Y = A^T Z summed across the waves
+//       in K1w's order, * 2^-s + bias, + skip, ReLU, cap, whole-line f32 stores.
+// Per accumulator the MFMA sequence is K1w's (k ascending; U_lo V_hi, U_hi V_lo, U_hi V_hi), V and Y are combined in K1w's order:
+// the two kernels agree BIT FOR BIT (tests/test_hip_parity.py::test_winograd_kernels_agree_bit_for_bit).
+#include "kernels.h"
+#include "device_common.h"
+
+#include <hip/hip_ext.h>
+
+namespace cattus {
+
+constexpr int W4_RP = 8 * SP + 64;            // pitch of a board row in a chunk image: 8 pixels of 144 B + 64 B (K1w's)
+constexpr int W4_IMG = 16 * W4_RP;            // one tile block's image: 2 boards x 8 rows = 19,456 B
+constexpr int W4_ZAREA = 4608;                // behind each image: its zero area (patch pixels off the board)
+constexpr int W4_IMGZ = W4_IMG + W4_ZAREA;    // 24,064 B
+constexpr int W4_DBUF = 2 * W4_IMGZ;          // a chunk buffer: both tile blocks = 48,128 B
+constexpr int W4_LDS_LOOP = 2 * W4_DBUF;      // 96,256 B
+constexpr int W4_LDS_Z = 4 * 2 * 64 * 256;    // the epilogue's exchange: [wave][c'][tile][64 couts f32] = 131,072 B
+constexpr int W4_LDS_TOTAL = W4_LDS_Z > W4_LDS_LOOP ? W4_LDS_Z : W4_LDS_LOOP;
+constexpr int W4_P = 5;                       // LDS-DMA pieces per wave and image: 4 x 5 = 20 >= the image's 19 KiB pieces
+static_assert(W4_IMG % 256 == 0 && W4_IMGZ % 256 == 0 && W4_DBUF % 256 == 0, "the zero area keeps a read's banks only if everything is 256-B aligned");
+
+__device__ __forceinline__ void w4_glds16(const char* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+typedef __attribute__((ext_vector_type(2))) _Float16 w4_f16x2;
+
+template <int V>
+using w4_int = std::integral_constant<int, V>;
+
+template <bool HAS_RES>
+__global__ void __launch_bounds__(256, 1)
+    conv3x3_wino4_kernel(const float* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
+                         const float* res, float* out, unsigned* __restrict__ sat, int cin, int cout) {
+    typedef _Float16 T;
+    typedef Mfma<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave = the frequency row it owns
+    const int lane = tid & 63;
+
+    const int nblk = gridDim.x, ncg = cout >> 6;
+    int logical = blockIdx.x;
+    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);  // one XCD: all cout groups of a range of boards
+    const int cout0 = (logical % ncg) * 64;   // the workgroup's 64 output channels
+    const int row0 = (logical / ncg) * 256;   // first tower row of its four boards
+
+    const int nch = cin >> 5;  // 32-channel chunks
+    const int nks = cin >> 4;  // k-steps
+    const uint32_t row_bytes = (uint32_t)cin * 4;
+
+    // ---- the U ring: slot l = the U stage (k-step, frequency 4 q + l) = [cb0 hi, cb0 lo, cb1 hi, cb1 lo] ----
+    const char* wb0 = reinterpret_cast<const char*>(wu) + ((size_t)(cout0 >> 5) * nks * 16 + 4 * q) * SW_STAGE;
+    const size_t wcb = (size_t)nks * 16 * SW_STAGE;  // from cout block 0 to cout block 1
+    const uint32_t voff0 = lane * 16;
+    u32x4 ring[4][4];
+    auto load_ustage = [&](u32x4(&slot)[4], const char* p0) __attribute__((always_inline)) {
+        const char* p1 = p0 + wcb;
+        u32x4 a, b, c, d;
+        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                     "global_load_dwordx4 %2, %4, %6\n\tglobal_load_dwordx4 %3, %4, %6 offset:1024"
+                     : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                     : "v"(voff0), "s"(p0), "s"(p1)
+                     : "memory");
+        slot[0] = a, slot[1] = b, slot[2] = c, slot[3] = d;
+    };
+
+    // ---- LDS-DMA of a chunk: per tile block an image of 16 board rows x 76 sixteen-byte pieces (8 pixels of 9 pieces: eight of
+    // data, the ninth re-reads the eighth; 4 pieces of padding that re-read too); the second board of an image sits one piece to
+    // the right.  1,216 pieces = 19 instructions of 64 per image; a wave issues 5 of each image (the 20th repeats the 19th) ----
+    const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
+    uint32_t off_a[W4_P];
+#pragma unroll
+    for (int i = 0; i < W4_P; i++) {
+        const int id = min(q * W4_P + i, 18);
+        const int sidx = id * 64 + lane, brow = sidx / 76, w = sidx - brow * 76, wsh = max(w - (brow >> 3), 0);
+        const int x = min(wsh / 9, 7), c = min(wsh - (wsh / 9) * 9, 7);
+        off_a[i] = (uint32_t)(brow * 8 + x) * row_bytes + c * 16;
+    }
+    const uint32_t dst_a0 = (uint32_t)min(q * W4_P, 18) * 1024;  // a wave's pieces are consecutive (the last wave's run stops at 18)
+    auto issue_chunk = [&](int ch, uint32_t dbuf) __attribute__((always_inline)) {  // chunk ch -> the buffer at dbuf
+        const char* src = abase0 + (size_t)ch * 128;
+#pragma unroll
+        for (int tb = 0; tb < 2; tb++)
+#pragma unroll
+            for (int i = 0; i < W4_P; i++) {
+                const uint32_t dst = dbuf + tb * W4_IMGZ + min(dst_a0 + i * 1024u, 18u * 1024u);
+                w4_glds16(src + (size_t)tb * 128 * row_bytes + off_a[i], dst);
+            }
+    };
+    for (int i = tid; i < 4 * (W4_ZAREA / 16); i += 256)  // the four zero areas
+        reinterpret_cast<f32x4*>(smem + (i / (W4_ZAREA / 16)) * W4_IMGZ + W4_IMG)[i % (W4_ZAREA / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // both first chunks go out ahead of the ring: every ring load is then younger than every DMA, as in the steady state
+    issue_chunk(0, 0);
+    issue_chunk(nch > 1 ? 1 : 0, W4_DBUF);
+    const char* wks = wb0;  // U of the k-step being multiplied
+#pragma unroll
+    for (int l = 0; l < 4; l++) load_ustage(ring[l], wks + (size_t)l * SW_STAGE);
+
+    // ---- the transform's geometry: lane = (tile n of the tile block, k-half hh): board n >> 4, tile row (n >> 2) & 3, column n & 3 ----
+    // Wave q combines the patch rows (ra, rb) of its tile: q = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 (B^T row q), as
+    // t = fma(d[rb], sg, d[ra]) with sg = +-1 (the product is exact: the bits of the sum / difference).  The patch pixel (r, c) is at
+    // image + tbase + r W4_RP + c SP; rows 0 / 3 and columns 0 / 3 can lie off the board: those reads go to the image's zero area at
+    // the read's own address mod 256 (the same banks) + the same offset -- folded into six base registers (row a / b x column
+    // class 0 / 1-2 / 3) that already point into the current chunk buffer.
+    const int n = lane & 31, hh = lane >> 5;
+    const int b2 = n >> 4, ty = (n >> 2) & 3, tx = n & 3;
+    const int ra = q == 0 ? 0 : q == 2 ? 2 : 1, rb = q == 3 ? 3 : q == 2 ? 1 : 2;
+    const float sg = q == 1 ? 1.0f : -1.0f;
+    uint32_t cur[2][3];
+    {
+        const int tbase = ((b2 * 8 + 2 * ty - 1) * W4_RP) + (2 * tx - 1) * SP + b2 * 16 + hh * 32;
+        const int tdelta = tbase - W4_IMG;
+        const int mra = (ra == 0 && ty == 0) ? 255 : -1, mrb = (rb == 3 && ty == 3) ? 255 : -1;
+        const int mc0 = tx != 0 ? -1 : 255, mc3 = tx != 3 ? -1 : 255;
+#pragma unroll
+        for (int X = 0; X < 2; X++) {
+            const int mr = X ? mrb : mra, rr = X ? rb : ra;
+            cur[X][0] = (uint32_t)(W4_IMG + (tdelta & mr & mc0) + rr * W4_RP);
+            cur[X][1] = (uint32_t)(W4_IMG + (tdelta & mr) + rr * W4_RP + SP);
+            cur[X][2] = (uint32_t)(W4_IMG + (tdelta & mr & mc3) + rr * W4_RP + 3 * SP);
+        }
+    }
+    int bufstep = W4_DBUF;  // cur[] += bufstep at every chunk change, bufstep = -bufstep
+
+    // V registers (MFMA B operands): [tb][l] for l = 0, 1; two sets [k-step parity][tb][l - 2] for l = 2, 3
+    u32x4 vh01[2][2], vl01[2][2], vh23[2][2][2], vl23[2][2][2];
+    f32x4 pa[4], pb[4], tt[4];  // the patch rows of a 4-channel group, and their combination (one f32x4 per patch column)
+    f32x4 xx;                   // a frequency's four values between the two halves of its slice
+    float vmax = 0.0f;
+
+    // The transform as a stream of PHASES (phase ph = 2 s + tb makes V of k-step s, tile block tb) of 24 slots each, one slot per MFMA
+    // gap; a phase handles its two 4-channel groups one after the other, the last frequency of a group being finished two slots into
+    // the next group's reads (so that nothing waits on the LDS):
+    //   slot 0, 1: read patch rows a, b of group 0      2, 3: frequency 3 of the PREVIOUS phase's group 1     4, 5: combine the rows
+    //   6..11: frequencies 0, 1, 2 (two slots each: the column combination + hi halves, then the lo halves)
+    //   12, 13: read rows of group 1     14, 15: frequency 3 of group 0     16, 17: combine     18..23: frequencies 0, 1, 2 of group 1
+    auto freq_slot = [&](int sp, int tbv, int g, int l, int half) __attribute__((always_inline)) {
+        // sp = parity of the k-step the phase makes V for (which l = 2,3 set), g = 4-channel group, l = frequency column
+        if (half == 0) {
+            xx = l == 0 ? tt[0] - tt[2] : l == 1 ? tt[1] + tt[2] : l == 2 ? tt[2] - tt[1] : tt[1] - tt[3];
+            // |x| <= 65504: x is a signed sum of four activations, capped where they were written at WINO_ACT_MAX = 65504 / 4
+            const w4_f16x2 h0 = __builtin_convertvector(__builtin_shufflevector(xx, xx, 0, 1), w4_f16x2);
+            const w4_f16x2 h1 = __builtin_convertvector(__builtin_shufflevector(xx, xx, 2, 3), w4_f16x2);
+            u32x4& dst = l < 2 ? vh01[tbv][l] : vh23[sp][tbv][l - 2];
+            dst[2 * g] = __builtin_bit_cast(uint32_t, h0);
+            dst[2 * g + 1] = __builtin_bit_cast(uint32_t, h1);
+        } else {
+            // lo = f16(x - hi), exact in f32: one mixed-precision fma per element (v_fma_mixlo/hi_f16), in asm -- the compiler rewrites the
+            // C form into convert - subtract - convert; the s_nop covers the partial-register write (kernels_wino.hip)
+            const u32x4& hsrc = l < 2 ? vh01[tbv][l] : vh23[sp][tbv][l - 2];
+            u32x4& dst = l < 2 ? vl01[tbv][l] : vl23[sp][tbv][l - 2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                uint32_t lo;
+                asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
+                    : "=&v"(lo)
+                    : "v"(hsrc[2 * g + p]), "v"(xx[2 * p]), "v"(xx[2 * p + 1]));
+                dst[2 * g + p] = lo;
+            }
+        }
+    };
+    auto read_row = [&](f32x4(&dstv)[4], int X, int tbv, int kp, int g) __attribute__((always_inline)) {
+        const int imm = tbv * W4_IMGZ + kp * 64 + g * 16;
+        dstv[0] = *reinterpret_cast<const f32x4*>(smem + cur[X][0] + imm);
+        dstv[1] = *reinterpret_cast<const f32x4*>(smem + cur[X][1] + imm);
+        dstv[2] = *reinterpret_cast<const f32x4*>(smem + cur[X][1] + imm + SP);
+        dstv[3] = *reinterpret_cast<const f32x4*>(smem + cur[X][2] + imm);
+    };
+    // slot j of phase (sp = parity of the target k-step, tbv); psp / ptb: the previous phase's
+    auto slot = [&](int sp, int tbv, int j) __attribute__((always_inline)) {
+        const int psp = tbv == 0 ? (sp ^ 1) : sp, ptb = tbv ^ 1;  // the phase before (s, tb0) is (s - 1, tb1); before (s, tb1): (s, tb0)
+        const int g = j / 12, jj = j % 12;
+        if (jj == 0) read_row(pa, 0, tbv, sp, g);
+        else if (jj == 1) read_row(pb, 1, tbv, sp, g);
+        else if (jj == 2 || jj == 3) {
+            if (g == 0) freq_slot(psp, ptb, 1, 3, jj - 2);
+            else freq_slot(sp, tbv, 0, 3, jj - 2);
+        } else if (jj == 4 || jj == 5) {
+#pragma unroll
+            for (int c = 2 * (jj - 4); c < 2 * (jj - 4) + 2; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) tt[c][e] = __builtin_fmaf(pb[c][e], sg, pa[c][e]);
+        } else {
+            freq_slot(sp, tbv, g, (jj - 6) >> 1, (jj - 6) & 1);
+        }
+    };
+
+    f32x16 acc[4][2][2];  // [l][tb][cb]
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[l][t2][c][e] = 0.0f;
+
+    // ---- prologue: chunk 0 has landed (everything but the ring's 16 loads and chunk 1's 10 pieces); phase (0, tb0) whole, the
+    // first half of phase (0, tb1) -- its second half sits in stages 0, 1 of k-step 0, where every later k-step has it ----
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(16 + 2 * W4_P) : "memory");
+#pragma unroll
+    for (int j = 0; j < 24; j++)
+        if (j != 2 && j != 3) slot(0, 0, j);  // (there is no phase before the first)
+#pragma unroll
+    for (int j = 0; j < 12; j++) slot(0, 1, j);
+
+    // One k-step: 8 stages of 6 MFMAs; SP_ = parity of the k-step (compile time), which fixes the l = 2,3 set, the chunk half the
+    // slices read and the wait counts.  `wnext`: U of the next k-step (clamped to the last: nobody uses those refills).
+    auto kstep = [&](const char* wnext, int ch_next, auto sp_tag) __attribute__((always_inline)) {
+        constexpr int SP_ = decltype(sp_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            // stage i: (tb, l) in the order (0,0) (0,1) (1,0) (1,1) (0,2) (0,3) (1,2) (1,3)
+            const int tbv = (i >> 1) & 1, l = (i & 1) + ((i >> 2) << 1);
+            const bool first_use = tbv == 0;
+            if (i == 2 && SP_ == 1) {
+                // the chunk change, in the middle of the odd k-step: every wave has read the last of chunk c (its phase (s, tb1) ended in
+                // stage 1) and has seen its own pieces of chunk c + 1 land (they are older than ring loads waited for since); behind the
+                // barrier chunk c + 1 is everybody's, chunk c's buffer takes chunk c + 2
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const uint32_t freed = (uint32_t)(bufstep > 0 ? 0 : W4_DBUF);  // the buffer cur[] pointed into until now
+#pragma unroll
+                for (int X = 0; X < 2; X++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) cur[X][k] += bufstep;
+                bufstep = -bufstep;
+                issue_chunk(ch_next, freed);
+            }
+            if (first_use) {
+                // all of this U stage's loads have returned: behind it in the queue are the refills of the slots freed since (l = 0: those
+                // of l = 1, 2, 3 of this k-step; l = 1: 2, 3; l = 2: 3 and the next k-step's 0, 1; l = 3: those two) -- and, in the odd k-step,
+                // the chunk's 2 W4_P pieces issued ahead of the next k-step's refills
+                constexpr int DMA = 2 * W4_P;
+                u32x4 r0 = ring[l][0], r1 = ring[l][1], r2 = ring[l][2], r3 = ring[l][3];
+                if (l == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                else if (l == 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                else if (l == 2 && SP_ == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                else if (l == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + DMA));
+                else if (SP_ == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + DMA));
+                ring[l][0] = r0, ring[l][1] = r1, ring[l][2] = r2, ring[l][3] = r3;
+            }
+            const frag uh0 = __builtin_bit_cast(frag, ring[l][0]), ul0 = __builtin_bit_cast(frag, ring[l][1]);
+            const frag uh1 = __builtin_bit_cast(frag, ring[l][2]), ul1 = __builtin_bit_cast(frag, ring[l][3]);
+            const frag vh = __builtin_bit_cast(frag, l < 2 ? vh01[tbv][l] : vh23[SP_][tbv][l - 2]);
+            const frag vl = __builtin_bit_cast(frag, l < 2 ? vl01[tbv][l] : vl23[SP_][tbv][l - 2]);
+            // the slices in this stage's six gaps: global gap 48 s + 6 i + e belongs to phase floor((gap + 36) / 24), slot (gap + 36) mod 24
+            const int gp = 6 * i + 36;
+            auto gap = [&](int e) __attribute__((always_inline)) {
+                const int ph = (gp + e) / 24, j = (gp + e) % 24;  // ph = 1: (s, tb1); 2: (s + 1, tb0); 3: (s + 1, tb1)
+                __builtin_amdgcn_sched_barrier(0);
+                slot(ph == 1 ? SP_ : SP_ ^ 1, ph == 2 ? 0 : 1, j);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            Mfma<T>::mac(ul0, vh, acc[l][tbv][0]);
+            gap(0);
+            Mfma<T>::mac(ul1, vh, acc[l][tbv][1]);
+            gap(1);
+            Mfma<T>::mac(uh0, vl, acc[l][tbv][0]);
+            gap(2);
+            Mfma<T>::mac(uh1, vl, acc[l][tbv][1]);
+            gap(3);
+            Mfma<T>::mac(uh0, vh, acc[l][tbv][0]);
+            gap(4);
+            Mfma<T>::mac(uh1, vh, acc[l][tbv][1]);
+            gap(5);
+            if (!first_use) load_ustage(ring[l], wnext + (size_t)l * SW_STAGE);  // the slot is free: the next k-step's stage
+        }
+    };
+    for (int c = 0; c < nch; c++) {
+        const char* w1 = wks + (size_t)16 * SW_STAGE;                                      // k-step 2c + 1
+        const char* w2 = wks + (size_t)(c + 1 < nch ? 32 : 16) * SW_STAGE;                 // k-step 2c + 2, or the last one again
+        kstep(w1, 0, w4_int<0>{});
+        kstep(w2, min(c + 2, nch - 1), w4_int<1>{});  // the chunk change inside fetches chunk c + 2 (or the last one again: nobody reads it)
+        wks = w2;
+    }
+    // the ring's last refills and the last DMA; the ring's registers are operands of the wait (kernels_wino.hip: to the compiler they
+    // are free from their last MFMA on, and it would park epilogue values in them while the loads are still on their way)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int l = 0; l < 4; l++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[l][0]), "+v"(ring[l][1]), "+v"(ring[l][2]), "+v"(ring[l][3])::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue ----
+    int elane = lane;  // everything the epilogue derives from the lane index comes from an opaque copy made here (kernels_wino.hip)
+    asm volatile("" : "+v"(elane));
+    const int en = elane & 31, eh = elane >> 5;
+    const int board = elane >> 4, pc = elane & 15;  // final layout: lane = (board, couts 4 pc .. 4 pc + 3) of one pixel position
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(bias + cout0 + pc * 4);
+    const f32x4 ds4 = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + pc * 4);
+    // wave q finishes tile row q of every board: pixel q * 16 + k of a board for k = 0..15 (y = 2 q + (k >> 3), x = k & 7)
+    const size_t orow = (size_t)row0 + board * 64 + q * 16;
+    f32x4 skip[16];
+    if (HAS_RES) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) skip[k] = *reinterpret_cast<const f32x4*>(res + (orow + k) * (size_t)cout + cout0 + pc * 4);
+    }
+    asm volatile("s_barrier" ::: "memory");  // every wave has left the chunk buffers (no LDS read of the loop is outstanding: they fed VALU work long done)
+    // Z[q][c'] = (row q of M) A: Z[.][0] = M[q][0] + M[q][1] + M[q][2], Z[.][1] = M[q][1] - M[q][2] - M[q][3] (K1w's order), four
+    // accumulator elements (couts 8 g + 4 eh ..) at a time, each accumulator read out of its AGPR by an asm statement
+    // exchange layout: [q][c'][tile 0..63][16 units of 4 couts], the unit index XORed with the tile's index inside its board
+#pragma unroll
+    for (int tbv = 0; tbv < 2; tbv++)
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                f32x4 m[4];
+#pragma unroll
+                for (int l = 0; l < 4; l++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[l][e]) : "a"(acc[l][tbv][cb][g * 4 + e]));
+                const f32x4 z0 = m[0] + m[1] + m[2], z1 = m[1] - m[2] - m[3];
+                const int unit = (cb * 8 + g * 2 + eh) ^ (en & 15);
+                char* zp = smem + ((size_t)(q * 2) * 64 + tbv * 32 + en) * 256 + (unit << 4);
+                *reinterpret_cast<f32x4*>(zp) = z0;
+                *reinterpret_cast<f32x4*>(zp + 64 * 256) = z1;
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int rp = k >> 3, txo = (k & 7) >> 1, cp = k & 1;  // output row parity inside the tile, tile column, output column parity
+        const int tile16 = q * 4 + txo;
+        const char* zb = smem + ((size_t)cp * 64 + board * 16 + tile16) * 256 + ((pc ^ tile16) << 4);
+        const f32x4 za = *reinterpret_cast<const f32x4*>(zb + (size_t)(rp + 0) * 2 * 64 * 256);
+        const f32x4 zc = *reinterpret_cast<const f32x4*>(zb + (size_t)(rp + 1) * 2 * 64 * 256);
+        const f32x4 zd = *reinterpret_cast<const f32x4*>(zb + (size_t)(rp + 2) * 2 * 64 * 256);
+        const f32x4 a = rp == 0 ? za + zc + zd : za - zc - zd;  // Y[0] = Z0 + Z1 + Z2, Y[1] = Z1 - Z2 - Z3
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float x = __builtin_fmaf(a[j], ds4[j], bias4[j]);  // the inverse weight scale is a power of two: the fma rounds once
+            if (HAS_RES) x = x + skip[k][j];
+            x = x > 0.0f ? x : 0.0f;
+            v[j] = x < WINO_ACT_MAX ? x : WINO_ACT_MAX;  // the next layer's transform relies on it
+        }
+        vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (orow + k) * (size_t)cout + cout0 + pc * 4));
+    }
+    if (vmax >= WINO_ACT_MAX) atomicAdd(sat, 1u);  // an activation reached the cap somewhere in this thread's share
+}
+
+bool wino4_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S) {
+    return S == 8 && cin >= 128 && cin % 32 == 0 && cout >= 128 && cout % 64 == 0 && bpad % 4 == 0;  // 64 filters: the resident tower
+}
+
+void launch_conv3x3_wino4(const float* in, const void* wu, const float* bias, const float* res, float* out, uint32_t bpad, uint32_t cin,
+                          uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat) {
+    typedef _Float16 H;
+    const dim3 grid((bpad / 4) * (cout / 64));
+    if (res)
+        hipExtLaunchKernelGGL((conv3x3_wino4_kernel<true>), grid, dim3(256), W4_LDS_TOTAL, st, ev_start, ev_stop, 0, in, (const H*)wu, bias, res, out,
+                              sat, (int)cin, (int)cout);
+    else
+        hipExtLaunchKernelGGL((conv3x3_wino4_kernel<false>), grid, dim3(256), W4_LDS_TOTAL, st, ev_start, ev_stop, 0, in, (const H*)wu, bias, res, out,
+                              sat, (int)cin, (int)cout);
+}
+
+hipError_t prepare_wino4() {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_TOTAL);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_TOTAL);
+    return err != hipSuccess ? err : e2;
+}
+
+}  // namespace cattus

@@ -206,7 +206,7 @@ class HipEvaluator:
         if tower_form is None:
             legacy = os.environ.get("CATTUS_WINOGRAD")
             tower_form = "auto" if not legacy else ("winograd" if legacy[0] == "1" else "direct")
-            if tower_form == "winograd" and not (dtype == "f16x2" and self.desc.board == 8 and self.desc.blocks > 0 and self.desc.filters % 128 == 0):
+            if tower_form == "winograd" and not (dtype == "f16x2" and self.desc.board == 8 and self.desc.blocks > 0 and self.desc.filters >= 128 and self.desc.filters % 64 == 0):
                 tower_form = "auto"  # the environment form was a wish ("where the shape allows it"); the config field is a demand
         if switches is None:
             switches = {k: os.environ[k] for k in DIAG_SWITCHES if k in os.environ}

@@ -35,14 +35,14 @@ pytestmark = pytest.mark.gpu
 BF16_MEASURED = {
     "chess_1x1": (4.6e-4, 1e-6), "chess_20x256": (7.5e-3, 1.15e-3), "chess_2x64": (2.2e-3, 3.5e-4), "chess_7x16": (3.9e-3, 2.0e-4),
     "hex11_1x1": (4.0e-4, 5.7e-5), "hex11_2x8": (1.1e-3, 3.5e-4), "hex4_7x16": (2.5e-3, 2.6e-4), "hex7_6x64": (3.2e-3, 5.8e-4),
-    "ttt_1x1": (2.3e-4, 1e-6), "ttt_2x64": (1.9e-3, 7.6e-4), "ttt_5x8": (2.7e-3, 7.4e-4),
+    "ttt_1x1": (2.3e-4, 1e-6), "ttt_2x64": (1.9e-3, 7.6e-4), "ttt_5x8": (2.7e-3, 7.4e-4), "chess_4x128": (4.0e-3, 6.0e-4),
 }
 BF16_FULL = {"20x256": (1.7e-2, 4.3e-3), "40x384": (5.2e-2, 1.2e-2)}
 # single-term f16 tower, the same way (round 4, profiles/r04_split_check.json): a tenth of bf16's error
 F16_MEASURED = {
     "chess_1x1": (3.2e-5, 1e-6), "chess_20x256": (7.5e-4, 7.6e-5), "chess_2x64": (2.1e-4, 4.0e-5), "chess_7x16": (3.7e-4, 3.0e-5),
     "hex11_1x1": (2.3e-5, 1e-6), "hex11_2x8": (7.2e-5, 1.3e-5), "hex4_7x16": (2.3e-4, 5.0e-5), "hex7_6x64": (3.7e-4, 5.6e-5),
-    "ttt_1x1": (1e-6, 1e-6), "ttt_2x64": (1.4e-4, 8.4e-5), "ttt_5x8": (2.3e-4, 5.4e-5),
+    "ttt_1x1": (1e-6, 1e-6), "ttt_2x64": (1.4e-4, 8.4e-5), "ttt_5x8": (2.3e-4, 5.4e-5), "chess_4x128": (4.0e-4, 6.0e-5),
 }
 # split precision against the float64 run of the reference network: measured max |dlogit| 7.4e-7, |dvalue| 2.1e-7 (chess
 # 20x256; the bit-exact f32 tower: 7.7e-7 / 1.9e-7, the reference's own f32 run: 3.3e-7 / 4.9e-8)
@@ -671,21 +671,28 @@ def test_device_pointer_entry_points_and_lanes_agree_with_host_entry_point():
         assert ev.lane_stream(0) != 0 and ev.lane_stream(0) != ev.lane_stream(1)
 
 
-# ---- the split tower in Winograd F(2x2, 3x3) form (kernels_wino.hip): f16x2 evaluators of 8x8-board networks with a multiple of 128
-# filters and max_batch >= 192 ----
+# ---- the split tower in Winograd F(2x2, 3x3) form: f16x2 evaluators of 8x8-board networks with a multiple of 64 filters (>= 128) and
+# max_batch >= 192 (or tower_form "winograd").  Two kernels, same bits: k4 = conv3x3_wino4_kernel (kernels_wino4.hip: 4 frequencies x
+# 2x2 blocks per wave, the default wherever it covers the shape), k16 = conv3x3_wino_kernel (kernels_wino.hip: 16 frequencies of one block) ----
 WINO_POLICY_ATOL_VS_F64, WINO_VALUE_ATOL_VS_F64 = 1.5e-6, 5e-7  # measured 5.1e-7 / 1.3e-7 (the direct split tower: 6.3e-7 / 2.1e-7)
+WINO_KERNELS = {"k4": "conv3x3_wino4_kernel", "k16": "conv3x3_wino_kernel"}
 
 
-def test_winograd_tower_within_the_reference_tolerance_and_batch_independent(monkeypatch):
+def wino_eval(blob, batch_size, wk, **more):
+    return HipEvaluator(blob, batch_size=batch_size, plane_words=1, dtype="f16x2", switches={"CATTUS_WINO_KERNEL": wk, **more})
+
+
+@pytest.mark.parametrize("wk", ["k4", "k16"])
+def test_winograd_tower_within_the_reference_tolerance_and_batch_independent(wk):
     """chess 20x256 (the reference-made fixture): with max_batch >= 192 the f16x2 tower runs its 40 layers behind the stem in
     Winograd form -- 2.25x fewer MFMAs, operands transformed in f32 / float64 and split into f16 pairs, f32 activations between the
     layers.  Inside the reference's cross-runtime bar (training/tests/test_net_output.py:28-33), as close to the reference's float64
-    run as the direct split tower, the same bits whatever the batch a leaf comes in, and selected by max_batch alone."""
+    run as the direct split tower, the same bits whatever the batch a leaf comes in, and selected by the configuration alone."""
     d, blob, z = blob_for("chess_20x256")
     planes = z["planes"]
     rep = np.concatenate([planes] * 50)[:197]
-    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
-        assert ev.tower_kernel() == "conv3x3_wino_kernel"
+    with wino_eval(blob, 256, wk) as ev:
+        assert ev.tower_kernel() == WINO_KERNELS[wk]
         p, v = ev.eval(planes)
         pr, vr = ev.eval(rep)
         assert ev.stats()["saturated"] == 0
@@ -693,16 +700,74 @@ def test_winograd_tower_within_the_reference_tolerance_and_batch_independent(mon
     assert np.abs(p - z["policy_f64"]).max() <= WINO_POLICY_ATOL_VS_F64 and np.abs(v - z["value_f64"]).max() <= WINO_VALUE_ATOL_VS_F64
     for i in range(len(rep)):  # a leaf's bits do not depend on the batch or the slot
         assert (pr[i] == p[i % len(planes)]).all() and vr[i] == v[i % len(planes)]
-    with HipEvaluator(blob, batch_size=128, plane_words=1, dtype="f16x2") as ev:
+    with HipEvaluator(blob, batch_size=128, plane_words=1, dtype="f16x2", switches={}) as ev:
         assert ev.tower_kernel() == "conv3x3_splitw_kernel"  # small batches: the direct kernels' small tiles
-    monkeypatch.setenv("CATTUS_WINOGRAD", "0")
-    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
+    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2", switches={}) as ev:
+        assert ev.tower_kernel() == "conv3x3_wino4_kernel"  # what cattus_hip_create chooses by itself
+    with HipEvaluator(blob, batch_size=16, plane_words=1, dtype="f16x2", tower_form="winograd", switches={"CATTUS_WINO_KERNEL": wk}) as ev:
+        assert ev.tower_kernel() == WINO_KERNELS[wk]  # the form is a field of the configuration: a 16-leaf evaluator in Winograd form ...
+        ps, vs = ev.eval(planes)
+    assert (ps == p).all() and (vs == v).all()  # ... gives a leaf the bits the 256-leaf evaluator gives it
+    with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2", tower_form="direct", switches={}) as ev:
         assert ev.tower_kernel() == "conv3x3_splitw_kernel"
         pd, vd = ev.eval(planes)
     assert np.abs(p - pd).max() < 2e-6 and np.abs(v - vd).max() < 1e-6  # the two forms of the same tower
 
 
-def test_winograd_tower_memory_plans_agree_bit_for_bit(monkeypatch):
+def test_winograd_tower_form_is_refused_where_no_kernel_covers_the_shape():
+    from cattus_amd.evaluator import CattusHipError
+
+    d = NetDesc(**hex_game(7), blocks=2, filters=128, vhc=16, phc=16)  # a 7x7 board
+    with pytest.raises(CattusHipError) as ei:
+        HipEvaluator(seeded_blob(d, 1), batch_size=16, plane_words=2, dtype="f16x2", tower_form="winograd", switches={})
+    assert ei.value.status == -2  # CATTUS_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("shape", [(3, 128, 256), (2, 192, 200), (2, 256, 24), (1, 384, 512)])
+def test_winograd_kernels_agree_bit_for_bit(shape):
+    """conv3x3_wino4_kernel against conv3x3_wino_kernel: per accumulator the same MFMA sequence, V and Y combined in the same order --
+    the same bits, on full, ragged and multi-round grids (192 filters: the 4-frequency kernel alone covers them, checked against the
+    direct form's tolerance instead)."""
+    blocks, filters, n = shape
+    d = NetDesc(**CHESS, blocks=blocks, filters=filters, vhc=8, phc=8)
+    blob = seeded_blob(d, 21)
+    planes = synth.random_chess_planes(n, 13)
+    with wino_eval(blob, max(n, 192), "k4") as ev:
+        assert ev.tower_kernel() == "conv3x3_wino4_kernel"
+        a = ev.eval(planes)
+        a2 = ev.eval(planes[: n // 3 + 1])
+        assert ev.stats()["saturated"] == 0
+    assert (a2[0] == a[0][: n // 3 + 1]).all() and (a2[1] == a[1][: n // 3 + 1]).all()
+    if filters % 128 == 0:
+        with wino_eval(blob, max(n, 192), "k16") as ev:
+            assert ev.tower_kernel() == "conv3x3_wino_kernel"
+            b = ev.eval(planes)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    else:
+        with HipEvaluator(blob, batch_size=max(n, 192), plane_words=1, dtype="f16x2", tower_form="direct", switches={}) as ev:
+            b = ev.eval(planes)
+        assert np.abs(a[0] - b[0]).max() < 2e-6 and np.abs(a[1] - b[1]).max() < 1e-6
+
+
+@pytest.mark.parametrize("wk", ["k4", "k16"])
+def test_winograd_tower_on_the_reference_made_fixture_with_the_reference_positions(wk):
+    """tests/golden/chess_4x128.npz: a Winograd-shaped network (8x8 board, 128 filters) evaluated by the reference's own module
+    (oracle/gen_golden.py) on the reference's five test FENs (training/tests/test_net_output.py:198-204) and 59 synthetic leaves.
+    Every leaf inside the reference's cross-runtime tolerance (test_net_output.py:28-33) and within the split tower's distance of
+    the reference's float64 run."""
+    d, blob, z = blob_for("chess_4x128")
+    planes = z["planes"]
+    assert len(planes) == 64
+    with wino_eval(blob, 256, wk) as ev:
+        assert ev.tower_kernel() == WINO_KERNELS[wk]
+        p, v = ev.eval(planes)
+        assert ev.stats()["saturated"] == 0
+    assert outputs_equal_ref_tol(p, v, z["policy"], z["value"])
+    assert np.abs(p - z["policy_f64"]).max() <= WINO_POLICY_ATOL_VS_F64 and np.abs(v - z["value_f64"]).max() <= WINO_VALUE_ATOL_VS_F64
+
+
+@pytest.mark.parametrize("wk", ["k4", "k16"])
+def test_winograd_tower_memory_plans_agree_bit_for_bit(wk):
     """The Winograd tower carves U of all layers and its activation buffers from one contiguous allocation (Infinity Cache page
     colouring) and writes a residual block's output over its own skip rows (two activation buffers per lane).
     Neither may change a bit: separate allocations (CATTUS_ARENA=0) and a third buffer (CATTUS_WINO_INPLACE=0) give the same
@@ -712,10 +777,8 @@ def test_winograd_tower_memory_plans_agree_bit_for_bit(monkeypatch):
     planes = synth.random_chess_planes(256, 12)
     got = {}
     for arena, inplace in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
-        monkeypatch.setenv("CATTUS_ARENA", arena)
-        monkeypatch.setenv("CATTUS_WINO_INPLACE", inplace)
-        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
-            assert ev.tower_kernel() == "conv3x3_wino_kernel"
+        with wino_eval(blob, 256, wk, CATTUS_ARENA=arena, CATTUS_WINO_INPLACE=inplace) as ev:
+            assert ev.tower_kernel() == WINO_KERNELS[wk]
             a = ev.eval(planes)
             b = ev.eval(planes[:77])  # the second call takes the other lane's buffers when the first one's are still warm
             c = ev.eval(planes)
@@ -729,23 +792,23 @@ def test_winograd_tower_memory_plans_agree_bit_for_bit(monkeypatch):
 
 @pytest.mark.parametrize("net,n,bound", [("20x256", 256, (3e-6, 1e-6)), ("40x384", 512, (1.2e-5, 2e-6))])
 def test_winograd_tower_tracks_the_f32_tower_at_full_size(net, n, bound):
-    """BASELINE configs 3 and 5 at full size in Winograd form against the bit-exact f32 tower, under the bounds the direct split
-    tower is held to (measured on 256 / 512 leaves: 1.1e-6 / 3.1e-7 and 3.5e-6 / 8e-7)."""
+    """BASELINE configs 3 and 5 at full size in Winograd form against the bit-exact f32 tower on EVERY leaf of the batch, under the
+    bounds the direct split tower is held to (measured on 256 / 512 leaves: 1.1e-6 / 3.1e-7 and 3.5e-6 / 8e-7)."""
     blocks, filters = (20, 256) if net == "20x256" else (40, 384)
     d = NetDesc(**CHESS, blocks=blocks, filters=filters, vhc=8, phc=8)
     blob = seeded_blob(d, 2 if net == "20x256" else 3)
     planes = synth.random_chess_planes(n, 2 if net == "20x256" else 3)
-    rows = np.random.default_rng(1).choice(n, size=24, replace=False)
     with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f32") as ev:
-        want_p, want_v = ev.eval(planes[rows])
-    with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f16x2") as ev:
-        assert ev.tower_kernel() == "conv3x3_wino_kernel"
+        want_p, want_v = ev.eval(planes)
+    with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f16x2", switches={}) as ev:
+        assert ev.tower_kernel() == "conv3x3_wino4_kernel"  # the kernel bench.py's headline is timed on
         got_p, got_v = ev.eval(planes)
     assert np.isfinite(got_p).all() and np.isfinite(got_v).all()
-    assert np.abs(got_p[rows] - want_p).max() <= bound[0] and np.abs(got_v[rows] - want_v).max() <= bound[1]
+    assert np.abs(got_p - want_p).max() <= bound[0] and np.abs(got_v - want_v).max() <= bound[1]
 
 
-def test_winograd_tower_counts_inputs_that_leave_the_f16_range():
+@pytest.mark.parametrize("wk", ["k4", "k16"])
+def test_winograd_tower_counts_inputs_that_leave_the_f16_range(wk):
     """The Winograd tower keeps f32 activations; what leaves the f16 range there is a TRANSFORMED input (up to four times an
     activation), so activations are capped at 65504 / 4 where they are written and counted like the direct tower's: 0 for a
     BatchNorm scale of 200, > 0 for 1e5."""
@@ -757,8 +820,8 @@ def test_winograd_tower_counts_inputs_that_leave_the_f16_range():
         t = seeded_tensors(d, 6)
         t["_conv1._bn.weight"] = t["_conv1._bn.weight"] * np.float32(scale)
         blob = pack_tensors(d, t)
-        with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2") as ev:
-            assert ev.tower_kernel() == "conv3x3_wino_kernel"
+        with wino_eval(blob, 256, wk) as ev:
+            assert ev.tower_kernel() == WINO_KERNELS[wk]
             p, v = ev.eval(planes)
             assert (ev.stats()["saturated"] > 0) == saturates
         assert np.isfinite(p).all() and np.isfinite(v).all()
