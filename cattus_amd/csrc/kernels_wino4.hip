@@ -27,6 +27,15 @@
 //       in K1w's order, * 2^-s + bias, + skip, ReLU, cap, whole-line f32 stores.
 // Per accumulator the MFMA sequence is K1w's (k ascending; U_lo V_hi, U_hi V_lo, U_hi V_hi), V and Y are combined in K1w's order:
 // the two kernels agree BIT FOR BIT (tests/test_hip_parity.py::test_winograd_kernels_agree_bit_for_bit).
+//
+// Where its time goes (round 5, scripts/stamps_w4.py and scripts/probes/w4_variant.py, profiles/r05_w4_anatomy.txt; chess 256 -> 256,
+// batch 256, cycles per wave at 1.85-1.93 GHz): prologue 6.3-7.1 k (first chunk from memory, V of k-step 0), loop 40.9-41.6 k,
+// ring drain 1.6 k, Z exchange 3.5 k, Y + stores 2.5 k.  The loop's floor is 24.6 k (768 MFMAs x 32); with the transform, the U ring and
+// the DMA taken out it runs in 26.3 k, and each of them adds what it costs when put back alone (transform 7.1 k, ring 4.0 k, DMA 5.0 k):
+// with ONE wave per SIMD nothing issues in an MFMA's shadow beyond ~24 cycles per gap, and a k-step carries ~350 instructions besides
+// its 48 MFMAs.  Without its MFMAs the loop still takes 32.6 k.  A second wave per SIMD is what would hide that stream, and 256
+// accumulator registers per wave rule it out (the designs with 128 were sized in DESIGN.md K1w4: none fits 256 registers with V in
+// registers, and V through LDS is LDS-bound).
 #include "kernels.h"
 #include "device_common.h"
 
@@ -42,21 +51,33 @@ constexpr int W4_DBUF = 2 * W4_IMGZ;          // a chunk buffer: both tile block
 constexpr int W4_LDS_LOOP = 2 * W4_DBUF;      // 96,256 B
 constexpr int W4_LDS_Z = 4 * 2 * 64 * 256;    // the epilogue's exchange: [wave][c'][tile][64 couts f32] = 131,072 B
 constexpr int W4_LDS_TOTAL = W4_LDS_Z > W4_LDS_LOOP ? W4_LDS_Z : W4_LDS_LOOP;
-constexpr int W4_P = 5;                       // LDS-DMA pieces per wave and image: 4 x 5 = 20 >= the image's 19 KiB pieces
 static_assert(W4_IMG % 256 == 0 && W4_IMGZ % 256 == 0 && W4_DBUF % 256 == 0, "the zero area keeps a read's banks only if everything is 256-B aligned");
 
+constexpr int W4_P = 5;  // LDS-DMA pieces per wave and image: 4 x 5 = 20 >= the image's 19 KiB pieces
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // "clobber list contains reserved registers: m0": intended, see below
 __device__ __forceinline__ void w4_glds16(const char* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    // LDS-DMA of 64 x 16 bytes, hidden from the compiler (kernels_wino.hip); M0 = the wave-uniform LDS byte address, declared clobbered
+    // (nothing else in this kernel lives in M0: no save / restore around each of the 10 pieces per chunk)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 typedef __attribute__((ext_vector_type(2))) _Float16 w4_f16x2;
 
 template <int V>
 using w4_int = std::integral_constant<int, V>;
+
+// ---- diagnostic build only (-DCATTUS_STAMPS, python -m cattus_amd.build --diag; scripts/stamps_w4.py): per-wave cycle stamps ----
+#ifdef CATTUS_STAMPS
+__device__ unsigned long long g_stamps_w4[1024 * 4 * 8];
+#define W4_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#define W4_STAMP_RT(i) st_[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define W4_STAMP(i)
+#define W4_STAMP_RT(i)
+#endif
 
 template <bool HAS_RES>
 __global__ void __launch_bounds__(256, 1)
@@ -66,6 +87,11 @@ __global__ void __launch_bounds__(256, 1)
     typedef Mfma<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef CATTUS_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    W4_STAMP(0);
+    W4_STAMP_RT(6);
     const int tid = threadIdx.x;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave = the frequency row it owns
     const int lane = tid & 63;
@@ -85,14 +111,20 @@ __global__ void __launch_bounds__(256, 1)
     const size_t wcb = (size_t)nks * 16 * SW_STAGE;  // from cout block 0 to cout block 1
     const uint32_t voff0 = lane * 16;
     u32x4 ring[4][4];
-    auto load_ustage = [&](u32x4(&slot)[4], const char* p0) __attribute__((always_inline)) {
+    // the four U stages of a k-step are 2 KiB apart: l = 0, 1 as immediate offsets from the k-step's base, l = 2, 3 from base + 4 KiB
+    // (two scalar additions per k-step and cout block instead of two per load)
+#define W4_ULOAD(OFF)                                                                                                                      \
+    asm volatile("global_load_dwordx4 %0, %4, %5 offset:" #OFF "\n\tglobal_load_dwordx4 %1, %4, %5 offset:" #OFF "+1024\n\t"             \
+                 "global_load_dwordx4 %2, %4, %6 offset:" #OFF "\n\tglobal_load_dwordx4 %3, %4, %6 offset:" #OFF "+1024"                  \
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)                                                                                  \
+                 : "v"(voff0), "s"(p0), "s"(p1)                                                                                            \
+                 : "memory")
+    auto load_ustage = [&](u32x4(&slot)[4], const char* pk, int l) __attribute__((always_inline)) {  // pk: the k-step's U (this wave's frequency row)
+        const char* p0 = pk + (l >> 1) * 4096;
         const char* p1 = p0 + wcb;
         u32x4 a, b, c, d;
-        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
-                     "global_load_dwordx4 %2, %4, %6\n\tglobal_load_dwordx4 %3, %4, %6 offset:1024"
-                     : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
-                     : "v"(voff0), "s"(p0), "s"(p1)
-                     : "memory");
+        if (l & 1) W4_ULOAD(2048);
+        else W4_ULOAD(0);
         slot[0] = a, slot[1] = b, slot[2] = c, slot[3] = d;
     };
 
@@ -123,10 +155,10 @@ __global__ void __launch_bounds__(256, 1)
         reinterpret_cast<f32x4*>(smem + (i / (W4_ZAREA / 16)) * W4_IMGZ + W4_IMG)[i % (W4_ZAREA / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
     // both first chunks go out ahead of the ring: every ring load is then younger than every DMA, as in the steady state
     issue_chunk(0, 0);
-    issue_chunk(nch > 1 ? 1 : 0, W4_DBUF);
+    issue_chunk(1, W4_DBUF);  // cin >= 128: at least four chunks
     const char* wks = wb0;  // U of the k-step being multiplied
 #pragma unroll
-    for (int l = 0; l < 4; l++) load_ustage(ring[l], wks + (size_t)l * SW_STAGE);
+    for (int l = 0; l < 4; l++) load_ustage(ring[l], wks, l);
 
     // ---- the transform's geometry: lane = (tile n of the tile block, k-half hh): board n >> 4, tile row (n >> 2) & 3, column n & 3 ----
     // Wave q combines the patch rows (ra, rb) of its tile: q = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 (B^T row q), as
@@ -137,7 +169,7 @@ __global__ void __launch_bounds__(256, 1)
     const int n = lane & 31, hh = lane >> 5;
     const int b2 = n >> 4, ty = (n >> 2) & 3, tx = n & 3;
     const int ra = q == 0 ? 0 : q == 2 ? 2 : 1, rb = q == 3 ? 3 : q == 2 ? 1 : 2;
-    const float sg = q == 1 ? 1.0f : -1.0f;
+    const float sg = q == 1 ? 1.0f : -1.0f;  // wave-uniform: an SGPR operand of the asm fma below
     uint32_t cur[2][3];
     {
         const int tbase = ((b2 * 8 + 2 * ty - 1) * W4_RP) + (2 * tx - 1) * SP + b2 * 16 + hh * 32;
@@ -161,11 +193,8 @@ __global__ void __launch_bounds__(256, 1)
     float vmax = 0.0f;
 
     // The transform as a stream of PHASES (phase ph = 2 s + tb makes V of k-step s, tile block tb) of 24 slots each, one slot per MFMA
-    // gap; a phase handles its two 4-channel groups one after the other, the last frequency of a group being finished two slots into
-    // the next group's reads (so that nothing waits on the LDS):
-    //   slot 0, 1: read patch rows a, b of group 0      2, 3: frequency 3 of the PREVIOUS phase's group 1     4, 5: combine the rows
-    //   6..11: frequencies 0, 1, 2 (two slots each: the column combination + hi halves, then the lo halves)
-    //   12, 13: read rows of group 1     14, 15: frequency 3 of group 0     16, 17: combine     18..23: frequencies 0, 1, 2 of group 1
+    // gap; a phase handles its two 4-channel groups one after the other (`slot` below).  Every LDS read issued during k-step s belongs
+    // to V of k-step s + 1.
     auto freq_slot = [&](int sp, int tbv, int g, int l, int half) __attribute__((always_inline)) {
         // sp = parity of the k-step the phase makes V for (which l = 2,3 set), g = 4-channel group, l = frequency column
         if (half == 0) {
@@ -181,14 +210,14 @@ __global__ void __launch_bounds__(256, 1)
             // C form into convert - subtract - convert; the s_nop covers the partial-register write (kernels_wino.hip)
             const u32x4& hsrc = l < 2 ? vh01[tbv][l] : vh23[sp][tbv][l - 2];
             u32x4& dst = l < 2 ? vl01[tbv][l] : vl23[sp][tbv][l - 2];
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                uint32_t lo;
-                asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
-                    : "=&v"(lo)
-                    : "v"(hsrc[2 * g + p]), "v"(xx[2 * p]), "v"(xx[2 * p + 1]));
-                dst[2 * g + p] = lo;
-            }
+            // both registers of the group in one statement, lo / lo / hi / hi: the write of a register's upper half follows the write of
+            // its lower half at a distance of one instruction (no s_nop), and nothing reads the pair before the MFMAs of a later stage
+            uint32_t lo0, lo1;
+            asm("v_fma_mixlo_f16 %0, -%2, 1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, -%3, 1.0, %6 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, -%2, 1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %1, -%3, 1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                : "=&v"(lo0), "=&v"(lo1)
+                : "v"(hsrc[2 * g]), "v"(hsrc[2 * g + 1]), "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(xx[3]));
+            dst[2 * g] = lo0, dst[2 * g + 1] = lo1;
         }
     };
     auto read_row = [&](f32x4(&dstv)[4], int X, int tbv, int kp, int g) __attribute__((always_inline)) {
@@ -198,22 +227,23 @@ __global__ void __launch_bounds__(256, 1)
         dstv[2] = *reinterpret_cast<const f32x4*>(smem + cur[X][1] + imm + SP);
         dstv[3] = *reinterpret_cast<const f32x4*>(smem + cur[X][2] + imm);
     };
-    // slot j of phase (sp = parity of the target k-step, tbv); psp / ptb: the previous phase's
+    // slot j of phase (sp = parity of the target k-step, tbv).  A group's twelve slots: 0, 1 combine its patch rows (read ten slots
+    // earlier: an LDS read that four waves issue at once takes ~200 cycles to come back, and a wave that waits for it stops issuing
+    // MFMAs); 2, 3 read the rows of the NEXT group (the next phase's group 0 behind group 1); 4..11 the four frequencies
     auto slot = [&](int sp, int tbv, int j) __attribute__((always_inline)) {
-        const int psp = tbv == 0 ? (sp ^ 1) : sp, ptb = tbv ^ 1;  // the phase before (s, tb0) is (s - 1, tb1); before (s, tb1): (s, tb0)
         const int g = j / 12, jj = j % 12;
-        if (jj == 0) read_row(pa, 0, tbv, sp, g);
-        else if (jj == 1) read_row(pb, 1, tbv, sp, g);
-        else if (jj == 2 || jj == 3) {
-            if (g == 0) freq_slot(psp, ptb, 1, 3, jj - 2);
-            else freq_slot(sp, tbv, 0, 3, jj - 2);
-        } else if (jj == 4 || jj == 5) {
+        if (jj < 2) {
 #pragma unroll
-            for (int c = 2 * (jj - 4); c < 2 * (jj - 4) + 2; c++)
+            for (int c = 2 * jj; c < 2 * jj + 2; c++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) tt[c][e] = __builtin_fmaf(pb[c][e], sg, pa[c][e]);
+                for (int e = 0; e < 4; e++) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(tt[c][e]) : "v"(pb[c][e]), "s"(sg), "v"(pa[c][e]));
+        } else if (jj < 4) {
+            // behind (s, tb0) comes (s, tb1), behind (s, tb1) comes (s + 1, tb0)
+            const int nsp = g == 0 || tbv == 0 ? sp : sp ^ 1, ntb = g == 0 ? tbv : tbv ^ 1, ng = g ^ 1;
+            if (jj == 2) read_row(pa, 0, ntb, nsp, ng);
+            else read_row(pb, 1, ntb, nsp, ng);
         } else {
-            freq_slot(sp, tbv, g, (jj - 6) >> 1, (jj - 6) & 1);
+            freq_slot(sp, tbv, g, (jj - 4) >> 1, (jj - 4) & 1);
         }
     };
 
@@ -227,12 +257,13 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[l][t2][c][e] = 0.0f;
 
-    // ---- prologue: chunk 0 has landed (everything but the ring's 16 loads and chunk 1's 10 pieces); phase (0, tb0) whole, the
-    // first half of phase (0, tb1) -- its second half sits in stages 0, 1 of k-step 0, where every later k-step has it ----
+    // ---- prologue: chunk 0 has landed (everything but the ring's 16 loads and chunk 1's 10 pieces); the rows of the first group, phase
+    // (0, tb0) whole, the first half of phase (0, tb1) -- its second half sits in stages 0, 1 of k-step 0, where every later k-step has it ----
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(16 + 2 * W4_P) : "memory");
+    read_row(pa, 0, 0, 0, 0);
+    read_row(pb, 1, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 24; j++)
-        if (j != 2 && j != 3) slot(0, 0, j);  // (there is no phase before the first)
+    for (int j = 0; j < 24; j++) slot(0, 0, j);
 #pragma unroll
     for (int j = 0; j < 12; j++) slot(0, 1, j);
 
@@ -245,10 +276,10 @@ __global__ void __launch_bounds__(256, 1)
             // stage i: (tb, l) in the order (0,0) (0,1) (1,0) (1,1) (0,2) (0,3) (1,2) (1,3)
             const int tbv = (i >> 1) & 1, l = (i & 1) + ((i >> 2) << 1);
             const bool first_use = tbv == 0;
-            if (i == 2 && SP_ == 1) {
-                // the chunk change, in the middle of the odd k-step: every wave has read the last of chunk c (its phase (s, tb1) ended in
-                // stage 1) and has seen its own pieces of chunk c + 1 land (they are older than ring loads waited for since); behind the
-                // barrier chunk c + 1 is everybody's, chunk c's buffer takes chunk c + 2
+            if (i == 0 && SP_ == 1) {
+                // the chunk change, at the start of the odd k-step: every LDS read issued during k-step s feeds V of k-step s + 1, so chunk c
+                // was last read in the even k-step; every wave has seen its own pieces of chunk c + 1 land (they are older than ring loads
+                // waited for since).  Behind the barrier chunk c + 1 is everybody's and chunk c's buffer takes chunk c + 2
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 const uint32_t freed = (uint32_t)(bufstep > 0 ? 0 : W4_DBUF);  // the buffer cur[] pointed into until now
 #pragma unroll
@@ -259,13 +290,14 @@ __global__ void __launch_bounds__(256, 1)
                 issue_chunk(ch_next, freed);
             }
             if (first_use) {
-                // all of this U stage's loads have returned: behind it in the queue are the refills of the slots freed since (l = 0: those
-                // of l = 1, 2, 3 of this k-step; l = 1: 2, 3; l = 2: 3 and the next k-step's 0, 1; l = 3: those two) -- and, in the odd k-step,
-                // the chunk's 2 W4_P pieces issued ahead of the next k-step's refills
+                // younger than this U stage: the refills of the slots freed since (l = 0: l = 1, 2, 3 of this k-step; l = 1: 2, 3; l = 2: 3 and the
+                // next k-step's 0, 1; l = 3: those two) -- and, in the odd k-step, the chunk's 2 W4_P pieces issued at its start
                 constexpr int DMA = 2 * W4_P;
                 u32x4 r0 = ring[l][0], r1 = ring[l][1], r2 = ring[l][2], r3 = ring[l][3];
-                if (l == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-                else if (l == 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                if (l == 0 && SP_ == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                else if (l == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + DMA));
+                else if (l == 1 && SP_ == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                else if (l == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + DMA));
                 else if (l == 2 && SP_ == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
                 else if (l == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + DMA));
                 else if (SP_ == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
@@ -296,18 +328,21 @@ __global__ void __launch_bounds__(256, 1)
             gap(4);
             Mfma<T>::mac(uh1, vh, acc[l][tbv][1]);
             gap(5);
-            if (!first_use) load_ustage(ring[l], wnext + (size_t)l * SW_STAGE);  // the slot is free: the next k-step's stage
+            if (!first_use) load_ustage(ring[l], wnext, l);  // the slot is free: the next k-step's stage
         }
     };
+    W4_STAMP(1);
     for (int c = 0; c < nch; c++) {
-        const char* w1 = wks + (size_t)16 * SW_STAGE;                                      // k-step 2c + 1
-        const char* w2 = wks + (size_t)(c + 1 < nch ? 32 : 16) * SW_STAGE;                 // k-step 2c + 2, or the last one again
+        const char* w1 = wks + (size_t)16 * SW_STAGE;                       // k-step 2c + 1
+        const char* w2 = wks + (size_t)(c + 1 < nch ? 32 : 16) * SW_STAGE;  // k-step 2c + 2, or the last one again
         kstep(w1, 0, w4_int<0>{});
         kstep(w2, min(c + 2, nch - 1), w4_int<1>{});  // the chunk change inside fetches chunk c + 2 (or the last one again: nobody reads it)
         wks = w2;
     }
-    // the ring's last refills and the last DMA; the ring's registers are operands of the wait (kernels_wino.hip: to the compiler they
-    // are free from their last MFMA on, and it would park epilogue values in them while the loads are still on their way)
+    W4_STAMP(2);
+    // the ring's last refills and the last DMA (nobody uses them: the loop's wait counts are the same in every k-step); the ring's registers
+    // are operands of the wait (kernels_wino.hip: to the compiler they are free from their last MFMA on, and it would park epilogue values
+    // in them while the loads are still on their way)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int l = 0; l < 4; l++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[l][0]), "+v"(ring[l][1]), "+v"(ring[l][2]), "+v"(ring[l][3])::"memory");
@@ -327,6 +362,7 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
         for (int k = 0; k < 16; k++) skip[k] = *reinterpret_cast<const f32x4*>(res + (orow + k) * (size_t)cout + cout0 + pc * 4);
     }
+    W4_STAMP(3);
     asm volatile("s_barrier" ::: "memory");  // every wave has left the chunk buffers (no LDS read of the loop is outstanding: they fed VALU work long done)
     // Z[q][c'] = (row q of M) A: Z[.][0] = M[q][0] + M[q][1] + M[q][2], Z[.][1] = M[q][1] - M[q][2] - M[q][3] (K1w's order), four
     // accumulator elements (couts 8 g + 4 eh ..) at a time, each accumulator read out of its AGPR by an asm statement
@@ -349,6 +385,7 @@ __global__ void __launch_bounds__(256, 1)
                 *reinterpret_cast<f32x4*>(zp + 64 * 256) = z1;
             }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    W4_STAMP(4);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int rp = k >> 3, txo = (k & 7) >> 1, cp = k & 1;  // output row parity inside the tile, tile column, output column parity
@@ -367,10 +404,26 @@ __global__ void __launch_bounds__(256, 1)
             v[j] = x < WINO_ACT_MAX ? x : WINO_ACT_MAX;  // the next layer's transform relies on it
         }
         vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (orow + k) * (size_t)cout + cout0 + pc * 4));
+        // plain stores: the rows are read again by the four cout-group workgroups of this board group in the next layer, which run on
+        // this XCD (the block-index map above) -- left in its L2 they cost 0.4 us per launch less than non-temporal ones (K1w: the reverse)
+        *reinterpret_cast<f32x4*>(out + (orow + k) * (size_t)cout + cout0 + pc * 4) = v;
     }
     if (vmax >= WINO_ACT_MAX) atomicAdd(sat, 1u);  // an activation reached the cap somewhere in this thread's share
+#ifdef CATTUS_STAMPS
+    W4_STAMP(5);
+    W4_STAMP_RT(7);
+    if (lane == 0 && blockIdx.x < 1024) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) g_stamps_w4[((size_t)blockIdx.x * 4 + q) * 8 + i] = st_[i];
+    }
+#endif
 }
+
+#ifdef CATTUS_STAMPS
+extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps_w4(unsigned long long* out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_w4), n * sizeof(unsigned long long));
+}
+#endif
 
 bool wino4_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S) {
     return S == 8 && cin >= 128 && cin % 32 == 0 && cout >= 128 && cout % 64 == 0 && bpad % 4 == 0;  // 64 filters: the resident tower
