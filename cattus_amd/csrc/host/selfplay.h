@@ -774,14 +774,19 @@ class SelfPlayRunner {
             recs.push_back(std::move(r));
         }
         std::lock_guard<std::mutex> lk(out_mu);
+        bool on_disk = true;  // every record of the game reached its file whole (fclose included: that is where a full disk shows)
         for (auto& r : recs) {
             const std::string& dir = r.dir == 0 ? d1 : d2;
             if (!dir.empty()) {
                 char name[64];
                 snprintf(name, sizeof name, "/%08u_%03u.traindata", r.game_idx, r.pos_idx);
                 FILE* f = fopen((dir + name).c_str(), "wb");
-                if (!f || fwrite(r.bytes.data(), 1, r.bytes.size(), f) != r.bytes.size()) s.error = "cannot write " + dir + name;
-                if (f) fclose(f);
+                const bool wrote = f && fwrite(r.bytes.data(), 1, r.bytes.size(), f) == r.bytes.size();
+                const bool closed = f && fclose(f) == 0;
+                if (!wrote || !closed) {
+                    s.error = "cannot write " + dir + name;
+                    on_disk = false;
+                }
             }
             if (records) records->push_back(std::move(r));
         }
@@ -795,7 +800,9 @@ class SelfPlayRunner {
             (w > 0 ? res.w1 : res.w2)++;
             tally = w > 0 ? 1 : 2;
         }
-        if (progress_) {  // behind the game's records: a line here means the game is complete on disk
+        // behind the game's records: a line here means the game is complete on disk -- so none is written for a game one of whose
+        // files failed (the supervisor then counts it unfinished and plays it again; the run itself reports s.error)
+        if (progress_ && on_disk) {
             fprintf(progress_, "%u %zu %d %d\n", s.game_idx, s.pairs.size(), tally, adjudicated ? 1 : 0);
             fflush(progress_);
         }

@@ -35,49 +35,6 @@
 
 namespace cattus {
 
-// Timing experiments only (scripts/build_variant.sh; the results are wrong with any of them set): WN_X_V4 reads the V fragments once
-// per four stages (what a wave owning 4 frequencies x 4 cout blocks would read), WN_X_NOTRANSFORM drops the transform slices from the
-// loop, WN_X_NOSTORE the output stores.
-#ifndef WN_X_V4
-#define WN_X_V4 0
-#endif
-#ifndef WN_X_NOTRANSFORM
-#define WN_X_NOTRANSFORM 0
-#endif
-// WN_X_AMOD: the same for the LDS-DMA of the activation chunks.  WN_X_UMOD: cache-policy bits of the U ring's loads (" nt", " sc0", " sc1", ...: results unchanged)
-#ifndef WN_X_AMODE
-#define WN_X_AMODE 0
-#endif
-#if WN_X_AMODE == 1
-#define WN_X_AMOD " nt"
-#elif WN_X_AMODE == 2
-#define WN_X_AMOD " sc1"
-#elif WN_X_AMODE == 3
-#define WN_X_AMOD " sc0 sc1"
-#else
-#define WN_X_AMOD ""
-#endif
-#ifndef WN_X_UMODE
-#define WN_X_UMODE 0
-#endif
-#if WN_X_UMODE == 1
-#define WN_X_UMOD " nt"
-#elif WN_X_UMODE == 2
-#define WN_X_UMOD " sc0"
-#elif WN_X_UMODE == 3
-#define WN_X_UMOD " sc1"
-#elif WN_X_UMODE == 4
-#define WN_X_UMOD " sc0 sc1"
-#else
-#define WN_X_UMOD ""
-#endif
-#ifndef WN_X_PLAINSTORE
-#define WN_X_PLAINSTORE 0
-#endif
-#ifndef WN_X_NOSTORE
-#define WN_X_NOSTORE 0
-#endif
-
 constexpr int WN_D = WINO_RING_STAGES;     // U stages in flight per wave (8 stages x 2 fragments x 4 VGPRs = 64 registers)
 constexpr int WN_VP = 80;                  // V image row: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad (b128 reads down 16 rows conflict-free)
 constexpr int WN_VF = 32 * WN_VP;          // one frequency: 32 tiles
@@ -91,17 +48,14 @@ constexpr int WN_DBUF = WN_DZERO + WN_ZAREA;  // 24,064 B
 static_assert(WN_DZERO % 256 == 0 && WN_DBUF % 256 == 0 && (2 * WN_VIMG) % 256 == 0, "the zero area keeps a read's banks only if it is 256-B aligned");
 constexpr int WN_LDS_D = 2 * WN_VIMG;
 constexpr int WN_LDS_TOTAL = WN_LDS_D + 2 * WN_DBUF;  // 130,048 B
-#ifndef WN_X_PA
-#define WN_X_PA 2
-#endif
-constexpr int WN_PA = WN_X_PA;             // stages of look-ahead on the V fragments
+constexpr int WN_PA = 2;                   // stages of look-ahead on the V fragments (1, 2 and 3 time the same since the conflict-free transform)
 constexpr int WN_P = 5;                    // LDS-DMA pieces per wave and chunk: 4 x 5 = 20 >= the image's 19 KiB pieces
 
 // LDS-DMA of 64 x 16 bytes, hidden from the compiler (it would otherwise order this wave's later LDS reads behind a vmcnt(0) of
 // its own, which also waits for the whole register ring): M0 = the wave-uniform LDS byte address, each lane its own source.
 __device__ __forceinline__ void glds16_asm(const char* gsrc, uint32_t lds_dst) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" WN_X_AMOD "\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
@@ -143,7 +97,7 @@ __global__ void __launch_bounds__(256, 1)
     u32x4 ring[D][2];
     auto load_stage = [&](u32x4(&slot)[2], const char* p) __attribute__((always_inline)) {
         u32x4 l0, l1;
-        asm volatile("global_load_dwordx4 %0, %2, %3" WN_X_UMOD "\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" WN_X_UMOD
+        asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
                      : "=&v"(l0), "=&v"(l1)
                      : "v"(voff0), "s"(p)
                      : "memory");
@@ -277,7 +231,6 @@ __global__ void __launch_bounds__(256, 1)
         frag vh[PR], vl[PR];
 #pragma unroll
         for (int q = 0; q < PA; q++) {
-            if (WN_X_V4 && q > 0) { vh[q] = vh[0], vl[q] = vl[0]; continue; }
             vh[q] = *reinterpret_cast<const frag*>(smem + vimg + q * WN_VF + vrd);
             vl[q] = *reinterpret_cast<const frag*>(smem + vimg + q * WN_VF + vrd + 32);
         }
@@ -285,12 +238,8 @@ __global__ void __launch_bounds__(256, 1)
         for (int f = 0; f < 16; f++) {
             const int cur = f % PR, nxt = (f + PA) % PR;
             if (f + PA < 16) {
-                if (!WN_X_V4 || ((f + PA) & 3) == 0) {
-                    vh[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd);
-                    vl[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd + 32);
-                } else {
-                    vh[nxt] = vh[(f + PA - 1) % PR], vl[nxt] = vl[(f + PA - 1) % PR];
-                }
+                vh[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd);
+                vl[nxt] = *reinterpret_cast<const frag*>(smem + vimg + (f + PA) * WN_VF + vrd + 32);
             }
             // all but the youngest 2 (D - 1) ring loads have returned -- plus, for the D stages whose own loads went out before this
             // body's LDS-DMA (issued between its stages 15 and 16), those WN_P younger DMA instructions
@@ -305,11 +254,11 @@ __global__ void __launch_bounds__(256, 1)
             const frag ul = __builtin_bit_cast(frag, ring[f % D][1]);
             Mfma<T>::mac(ul, vh[cur], acc[f]);
             __builtin_amdgcn_sched_barrier(0);
-            if (!WN_X_NOTRANSFORM) transform_slice(f, 0, dbase, kp, vnext);
+            transform_slice(f, 0, dbase, kp, vnext);
             __builtin_amdgcn_sched_barrier(0);
             Mfma<T>::mac(uh, vl[cur], acc[f]);
             __builtin_amdgcn_sched_barrier(0);
-            if (!WN_X_NOTRANSFORM) transform_slice(f, 1, dbase, kp, vnext);
+            transform_slice(f, 1, dbase, kp, vnext);
             __builtin_amdgcn_sched_barrier(0);
             Mfma<T>::mac(uh, vh[cur], acc[f]);
             // refill D stages ahead: chunk pointer + a constant (two scalar instructions; clamped to the layer's last stage it was a
@@ -410,13 +359,7 @@ __global__ void __launch_bounds__(256, 1)
             v[j] = x < WINO_ACT_MAX ? x : WINO_ACT_MAX;  // the next layer's transform relies on it (and counts nothing itself)
         }
         vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-        if (WN_X_NOSTORE && v[0] != 12345.678f) continue;
-        f32x4* dst = reinterpret_cast<f32x4*>(out + ((size_t)row0 + px) * (size_t)cout + cout0 + pc * 4);
-        if (WN_X_PLAINSTORE) {
-            *dst = v;
-            continue;
-        }
-        __builtin_nontemporal_store(v, dst);
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + ((size_t)row0 + px) * (size_t)cout + cout0 + pc * 4));
     }
     if (vmax >= WINO_ACT_MAX) atomicAdd(sat, 1u);  // an activation reached the cap somewhere in this thread's share
 }

@@ -85,20 +85,50 @@ def pool_from_dirs(out_dir1, out_dir2, record_bytes: int):
     return recs, meta
 
 
+def stale_state(work_dir) -> list[str]:
+    """What an earlier round left in a work directory: progress lines, counters, re-queue lists, pooled records, record files.
+    Any of it would be read as THIS round's (progress files are appended to, a game with a progress line is never played again,
+    pool_from_dirs pools every .traindata it finds): a second round in the same directory would hand the trainer the first round's
+    records -- old-network data -- and count a dead rank's games as done."""
+    work = Path(work_dir)
+    found = [str(p.relative_to(work)) for pat in ("progress/*.txt", "rank*.json", "requeue*", "pooled.npz", "round.npz", ABORT_FLAG)
+             for p in sorted(work.glob(pat))]
+    for d in ("out1", "out2"):
+        n = sum(1 for _ in (work / d).glob("*.traindata")) if (work / d).is_dir() else 0
+        if n:
+            found.append(f"{d}/ ({n} records)")
+    return found
+
+
+def wipe_state(work_dir) -> None:
+    work = Path(work_dir)
+    for pat in ("progress/*.txt", "rank*.json", "requeue*", "pooled.npz", "round.npz", ABORT_FLAG, "out1/*.traindata", "out2/*.traindata"):
+        for p in work.glob(pat):
+            p.unlink()
+
+
 def supervise(rank_cmd, world: int, games_num: int, work_dir, *, max_requeues: int = 2, rank_timeout: float | None = None,
-              env_extra: dict | None = None, log=sys.stderr) -> dict:
+              env_extra: dict | None = None, log=sys.stderr, stale: str = "refuse") -> dict:
     """Run `world` rank processes, contain the ones that fail, return the round's summary.
 
     rank_cmd(rank, requeue_list_file | None) -> argv of one rank process.  A regular rank gets RANK / WORLD_SIZE /
     LOCAL_RANK / MASTER_* in its environment (what torch.distributed.run would set); a re-queue child runs alone
     (WORLD_SIZE=1) with CATTUS_LOCAL_DEVICE naming the dead rank's device, and takes its games from the list file.
     Progress files: <work_dir>/progress/rank<r>.txt and requeue<r>_<attempt>.txt; a rank writes <work_dir>/rank<r>.json
-    (its own counters) when its games are done."""
+    (its own counters) when its games are done.
+
+    A work directory serves ONE round: state of an earlier one (`stale_state`) is refused (stale="refuse", the default) or removed
+    first (stale="wipe"); nothing of it is ever pooled.  rank_timeout: seconds after which ranks still running are killed and their
+    unfinished games re-queued (a rank wedged in a GPU call never exits by itself)."""
     work = Path(work_dir)
+    old = stale_state(work)
+    if old and stale == "wipe":
+        wipe_state(work)
+    elif old:
+        raise RuntimeError(f"{work} holds the state of an earlier round ({', '.join(old[:6])}{' ...' if len(old) > 6 else ''}): "
+                           "a work directory serves one round -- use a fresh one, or stale='wipe' / --clean")
     (work / "progress").mkdir(parents=True, exist_ok=True)
     flag = work / ABORT_FLAG
-    if flag.exists():
-        flag.unlink()
     port = free_port()
     base_env = dict(os.environ)
     base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -130,8 +160,12 @@ def supervise(rank_cmd, world: int, games_num: int, work_dir, *, max_requeues: i
                     status[r] = -9
             flag.write_text("timeout\n")
         time.sleep(0.05)
-    # a rank is complete when it exited cleanly AND reported its counters (its games are all on disk)
-    failed = [r for r in range(world) if status[r] != 0 or not (work / f"rank{r}.json").exists()]
+    # a rank is complete when it reported its counters (written behind its last game: all of them are on disk) and either exited
+    # cleanly or was only stopped while waiting for a dead peer in the pooling collective (killed at the rank timeout, a failed
+    # collective): what it was there to do is done, nothing of its shard is re-queued
+    done0 = read_progress(sorted((work / "progress").glob("*.txt")))
+    failed = [r for r in range(world)
+              if not (work / f"rank{r}.json").exists() or (status[r] != 0 and any(g not in done0 for g in shard_of(r, world, games_num)))]
     requeued: list[int] = []
     attempts = {r: 0 for r in failed}
     pending = list(failed)
@@ -150,7 +184,7 @@ def supervise(rank_cmd, world: int, games_num: int, work_dir, *, max_requeues: i
         env = dict(base_env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(free_port()), CATTUS_SUPERVISED="1", CATTUS_LOCAL_DEVICE=str(r),
                    CATTUS_REQUEUE_TAG=f"requeue{r}_{attempts[r]}")
-        for k in ("CATTUS_FAULT_RANK", "CATTUS_FAULT_AFTER_GAMES"):  # an injected fault (tests) belongs to the first life only
+        for k in ("CATTUS_FAULT_RANK", "CATTUS_FAULT_AFTER_GAMES", "CATTUS_HANG_RANK"):  # an injected fault (tests) belongs to the first life only
             env.pop(k, None)
         rc = subprocess.call(rank_cmd(r, str(lst)), env=env, stdout=sys.stderr)
         if rc != 0:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# An experimental build of one translation unit: scripts/build_variant.sh NAME "-DWN_X=1 ..." [kernels_wino]
+# A build of one translation unit with extra flags (e.g. the diagnostic stamps): scripts/build_variant.sh NAME "-DCATTUS_STAMPS" [kernels_wino4]
 # -> cattus_amd/libcattus_hip_NAME.so (selected at run time with CATTUS_HIP_LIB), the other objects from the regular build.
 set -e
 cd "$(dirname "$0")/.."

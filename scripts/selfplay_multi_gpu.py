@@ -51,6 +51,10 @@ def parse_args(argv=None):
     ap.add_argument("--work-dir", default=None, help="out1/, out2/ (.traindata files), progress/ and the ranks' counters; default: a temporary directory")
     ap.add_argument("--pg-timeout", type=float, default=600.0, help="deadline in seconds of every collective")
     ap.add_argument("--max-requeues", type=int, default=2)
+    ap.add_argument("--rank-timeout", type=float, default=None,
+                    help="supervisor: seconds after which ranks still running are killed and their unfinished games re-queued (a rank "
+                         "wedged in a GPU call never exits by itself); default: none")
+    ap.add_argument("--clean", action="store_true", help="supervisor: remove what an earlier round left in --work-dir (default: refuse to run there)")
     ap.add_argument("--game-list-file", default=None, help="(set by the supervisor) play exactly the global game indices listed in this file")
     ap.add_argument("--out", default=None)
     return ap.parse_args(argv)
@@ -86,7 +90,8 @@ def supervisor_main(args, argv):
         return cmd
 
     t0 = time.perf_counter()
-    summary = supervisor.supervise(rank_cmd, world, args.games_num, work, max_requeues=args.max_requeues)
+    summary = supervisor.supervise(rank_cmd, world, args.games_num, work, max_requeues=args.max_requeues, rank_timeout=args.rank_timeout,
+                                   stale="wipe" if args.clean else "refuse")
     info = sp.game_info(args.game)
     pooled = work / "pooled.npz"
     if summary["pooled_via"] == "collective" and pooled.exists():
@@ -190,8 +195,11 @@ def rank_main(args):
 
         threading.Thread(target=die_after_k, daemon=True).start()
 
-    if use_pg:
-        dist.barrier()
+    if os.environ.get("CATTUS_HANG_RANK") is not None and int(os.environ["CATTUS_HANG_RANK"]) == rank and not requeue:
+        time.sleep(3600)  # fault injection (tests): a rank wedged before it plays -- only --rank-timeout ends it
+    if use_pg and os.environ.get("CATTUS_SUPERVISED") != "1":
+        dist.barrier()  # a common start for the timing.  Not under the supervisor: a peer that died or hangs before it would take every
+        # healthy rank down with it (round-4 review) -- there each rank plays its shard at once and meets the others in the collective
     t0 = time.perf_counter()
     res = sp.run_self_play(args.game, cfg, net, None, local_games, out1, out2)
     t_play = time.perf_counter() - t0

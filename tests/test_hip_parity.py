@@ -320,6 +320,30 @@ def test_resident_tower_row_splits_agree(monkeypatch):
             assert (one_p[0] == want_p[77]).all() and one_v[0] == want_v[77], (ch, ls)
 
 
+def test_resident_split_tower_workgroup_shapes_agree_from_512_boards_up():
+    """tower64_split_kernel picks its workgroup shape PER LAUNCH from the batch's row count: two boards per workgroup from 512
+    boards up, one below (kernels_t64s.hip).  A leaf's bits must not depend on that: an evaluator of 640 boards (hex7 6x64) under
+    every forced shape (CATTUS_T64S_SHAPE=1 / 2 / 9), on a full batch (two-board workgroups by default), a 300-leaf batch (one-board
+    workgroups) and a single leaf, against the per-layer launches (CATTUS_TOWER64=0)."""
+    d = NetDesc(**hex_game(7), blocks=6, filters=64, vhc=16, phc=16)
+    blob = seeded_blob(d, 29)
+    n = 640
+    planes = synth.random_hex_planes(n, 7, 29)
+    with HipEvaluator(blob, batch_size=n, plane_words=2, dtype="f16x2", switches={"CATTUS_TOWER64": "0"}) as ev:
+        assert ev.tower_kernel() == "conv3x3_splitw_kernel"
+        want_p, want_v = ev.eval(planes)
+    for shape in (None, "1", "2", "9"):
+        with HipEvaluator(blob, batch_size=n, plane_words=2, dtype="f16x2", switches={"CATTUS_T64S_SHAPE": shape} if shape else {}) as ev:
+            assert ev.tower_kernel() == "tower64_split_kernel"
+            got_p, got_v = ev.eval(planes)
+            assert (got_p == want_p).all() and (got_v == want_v).all(), shape
+            part_p, part_v = ev.eval(planes[100:400])  # 300 boards: below the switch
+            assert (part_p == want_p[100:400]).all() and (part_v == want_v[100:400]).all(), shape
+            one_p, one_v = ev.eval(planes[555:556])
+            assert (one_p[0] == want_p[555]).all() and one_v[0] == want_v[555], shape
+            assert ev.stats()["saturated"] == 0
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("name", ["chess_20x256", "hex11_2x8"])
 def test_fused_stem_equals_separate_plane_pack(name, dtype, monkeypatch):

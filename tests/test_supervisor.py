@@ -99,3 +99,37 @@ def test_launcher_world_size_must_match_gpus(tmp_path):
     p = subprocess.run([sys.executable, str(SCRIPT), "--gpus", "2", "--game", "hex4", "--net", "stub", "--games-num", "4", "--sim-num", "20"],
                        cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def test_a_second_round_in_the_same_work_directory_is_refused_or_cleaned(tmp_path):
+    """A work directory serves one round (round-4 review): a second round there would append to the first one's progress files, pool its
+    record files and count a dead rank's games as done -- old-network data for the trainer.  Refused by default; --clean removes the
+    earlier state first, and then the round is the new seed's, byte for byte."""
+    p, work, out = _run(tmp_path, 2, 8, extra_args=("--seed", "1"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    first = np.load(work / "round.npz")["recs"].copy()
+    assert supervisor.stale_state(work)
+    # the same directory again, another seed, rank 1 dying at once: refused before any rank starts
+    p2, _, _ = _run(tmp_path, 2, 8, extra_env={"CATTUS_FAULT_RANK": "1"}, extra_args=("--seed", "7"))
+    assert p2.returncode != 0 and "earlier round" in p2.stderr
+    assert (np.load(work / "round.npz")["recs"] == first).all()  # untouched
+    p3, _, out3 = _run(tmp_path, 2, 8, extra_args=("--seed", "7", "--clean"))
+    assert p3.returncode == 0, p3.stderr[-3000:]
+    whole = sp.run_self_play("hex4", sp.make_config(sim_num=20, batch_size=4, threads=1, seed=7), sp.Net.stub("hex4"), None, 8)
+    z = np.load(work / "round.npz")
+    assert (z["meta"] == whole["record_meta"]).all() and (z["recs"] == whole["record_bytes"]).all()
+    assert json.loads(out3.read_text())["requeued_games"] == []
+
+
+def test_rank_that_hangs_is_killed_at_the_rank_timeout_and_its_games_requeued(tmp_path):
+    """--rank-timeout reaches supervise(): a rank that never exits (here: SIGSTOPped by the fault hook's sibling, a sleep far beyond
+    the timeout) is killed, its unfinished games are played by a fresh process, the round is whole."""
+    games = 8
+    p, work, out = _run(tmp_path, 2, games, extra_env={"CATTUS_HANG_RANK": "1"}, extra_args=("--rank-timeout", "8"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    s = json.loads(out.read_text())
+    assert s["failed_ranks"] == [1] and s["rank_status"]["1"] == -9 and s["pooled_via"] == "files"
+    assert s["requeued_games"] == list(range(1, games, 2))
+    whole = _single_process(games)
+    z = np.load(work / "round.npz")
+    assert (z["meta"] == whole["record_meta"]).all() and (z["recs"] == whole["record_bytes"]).all()
