@@ -24,7 +24,10 @@ ABI_SYMBOLS = [
     "cattus_pool_reduce_counters",
     "cattus_pool_free",
     "cattus_pool_last_error",
+    "cattus_pool_set_timeout",
+    "cattus_pool_debug_stalled_collective",
 ]
+E_STATE, E_TIMEOUT = -5, -6  # CATTUS_POOL_E_STATE, CATTUS_POOL_E_TIMEOUT
 
 _lib = None
 
@@ -46,13 +49,21 @@ def load_library():
     L.cattus_pool_free.argtypes = [vp]
     L.cattus_pool_free.restype = None
     L.cattus_pool_last_error.restype = C.c_char_p
+    L.cattus_pool_set_timeout.argtypes = [vp, C.c_double]
+    L.cattus_pool_debug_stalled_collective.argtypes = [vp]
     _lib = L
     return L
 
 
+class PoolError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"cattus_pool status {status}: {message}")
+        self.status = status
+
+
 def _check(rc: int):
     if rc != 0:
-        raise RuntimeError(f"cattus_pool status {rc}: {load_library().cattus_pool_last_error().decode(errors='replace')}")
+        raise PoolError(rc, load_library().cattus_pool_last_error().decode(errors="replace"))
 
 
 def unique_id() -> bytes:
@@ -75,6 +86,15 @@ class Pool:
         if getattr(self, "_h", None):
             self._lib.cattus_pool_destroy(self._h)
             self._h = None
+
+    def set_timeout(self, seconds: float):
+        """Deadline of every wait inside this pool's entry points: past it they return CATTUS_POOL_E_TIMEOUT (PoolError.status == E_TIMEOUT)
+        and the communicator is aborted."""
+        _check(self._lib.cattus_pool_set_timeout(self._h, float(seconds)))
+
+    def debug_stalled_collective(self):
+        """Diagnostic: a collective that does not complete (what the pooling collectives are to the survivors of a dead peer)."""
+        _check(self._lib.cattus_pool_debug_stalled_collective(self._h))
 
     def __enter__(self):
         return self

@@ -11,6 +11,15 @@
  *
  * Every entry point returns 0 or a negative status; cattus_pool_last_error() gives the calling thread's last message.
  * Nothing here is on the evaluation path.
+ *
+ * Failure path: no entry point hangs.  The communicator is non-blocking (ncclCommInitRankConfig, blocking = 0) and every wait
+ * inside an entry point -- for RCCL to finish what a call started, for the collective's kernels to leave the stream -- is a poll
+ * with a deadline (cattus_pool_set_timeout; 600 s by default).  When a peer has died or never calls, the deadline passes:
+ * the communicator is aborted (ncclCommAbort, which also ends its kernels on the device), the entry point returns
+ * CATTUS_POOL_E_TIMEOUT, and the handle is dead: every later call on it returns CATTUS_POOL_E_STATE, cattus_pool_destroy frees it.
+ * The caller's output arguments are written only by a call that returns 0.  What a host does then is the supervisor's recipe
+ * (cattus_amd/supervisor.py): the shard's records are on disk already, the dead rank's games are re-queued, a new pool is made.
+ * The reference leaves a dead worker undetected (training/self-play/src/self_play.rs:128, its own TODO).
  */
 #ifndef CATTUS_POOL_H
 #define CATTUS_POOL_H
@@ -23,6 +32,8 @@ extern "C" {
 #endif
 
 #define CATTUS_POOL_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
+#define CATTUS_POOL_E_STATE (-5)   /* the pool's communicator was aborted by an earlier failure */
+#define CATTUS_POOL_E_TIMEOUT (-6) /* a wait passed its deadline: a peer is gone or never called; the communicator is aborted */
 
 typedef struct cattus_pool cattus_pool;
 
@@ -33,6 +44,13 @@ int cattus_pool_unique_id(uint8_t id[CATTUS_POOL_ID_BYTES]);
 /* One communicator per process: rank `rank` of `world` on HIP device `device` (ncclCommInitRank; collective: every rank calls). */
 int cattus_pool_create(const uint8_t id[CATTUS_POOL_ID_BYTES], int rank, int world, int device, cattus_pool** out);
 void cattus_pool_destroy(cattus_pool* p);
+/* Deadline, in seconds, of every wait inside the entry points of this pool (>= 0; 600 by default; cattus_pool_create itself
+ * waits at most the default for the other ranks). */
+int cattus_pool_set_timeout(cattus_pool* p, double seconds);
+/* Diagnostic, for tests of the failure path: a collective that does not complete (the pool's stream is held while an all-reduce
+ * waits behind it -- with one rank RCCL leaves nothing unmatched) returns what a collective returns when a peer never calls:
+ * CATTUS_POOL_E_TIMEOUT after the pool's timeout, the communicator aborted, the stream drained. */
+int cattus_pool_debug_stalled_collective(cattus_pool* p);
 
 /* Collective.  bytes [n_local][record_bytes] and meta [n_local][3] = (game_idx, pos_idx, dir) as cattus_sp_result_records
  * returns them.  On rank 0: *all_bytes / *all_meta receive malloc'ed arrays of *n_total records sorted by (game, ply) -- free

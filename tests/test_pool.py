@@ -40,3 +40,28 @@ def test_one_rank_pooling_over_rccl():
             res["player1_wins"], res["player2_wins"], res["draws"], 2**40 + 5]
     with pytest.raises(RuntimeError):
         pool.Pool(pool.unique_id(), 1, 1, 0)  # rank out of range
+
+
+@pytest.mark.gpu
+def test_a_collective_nobody_matches_returns_a_timeout_status_instead_of_hanging():
+    """The failure path (include/cattus_pool.h): the communicator is non-blocking and every wait has a deadline.  A collective
+    that does not complete -- what a pooling collective is to the survivors when a peer died before calling it (the reference's TODO,
+    training/self-play/src/self_play.rs:128); with one rank: an all-reduce behind a held stream, RCCL refuses a lone self-receive --
+    returns CATTUS_POOL_E_TIMEOUT once a 0-second deadline has passed, the communicator
+    is aborted, the handle answers CATTUS_POOL_E_STATE from then on and is destroyed without a hang; a new pool works."""
+    import time
+
+    p = pool.Pool(pool.unique_id(), 0, 1, 0)
+    assert p.reduce_counters([1, 2, 3]) == [1, 2, 3]  # alive
+    p.set_timeout(0.0)
+    t0 = time.monotonic()
+    with pytest.raises(pool.PoolError) as ei:
+        p.debug_stalled_collective()
+    assert ei.value.status == pool.E_TIMEOUT, str(ei.value)
+    assert time.monotonic() - t0 < 30
+    with pytest.raises(pool.PoolError) as ei:
+        p.reduce_counters([1])
+    assert ei.value.status == pool.E_STATE
+    p.close()
+    with pool.Pool(pool.unique_id(), 0, 1, 0) as q:
+        assert q.reduce_counters([5]) == [5]
