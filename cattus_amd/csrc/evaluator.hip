@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -242,6 +243,11 @@ struct Lane {
     DevBuf d_legal_idx, d_legal_cnt, d_probs;  // legal-move softmax operands, allocated on first use
     uint32_t legal_stride = 0;
     PinnedBuf h_planes, h_policy, h_value;
+    // the Winograd tower in one launch (tower_wino4_kernel): this lane's layer table, hand-off counters and error word, and the
+    // page-locked word the error word is copied to behind every such launch
+    DevBuf tower_layers, tower_ready, tower_err;
+    PinnedBuf h_tower_err;
+    uint32_t tower_nlayers = 0;
     std::mutex mu;  // held while a batch uses the lane
     ~Lane() {
         if (done) (void)hipEventDestroy(done);
@@ -285,6 +291,13 @@ struct cattus_eval {
     // which Winograd kernel: the 4-frequencies x 2x2-blocks one (kernels_wino4.hip) wherever it covers the shape, else the
     // 16-frequencies one (kernels_wino.hip); same bits; diagnostic switch CATTUS_WINO_KERNEL=k16|k4
     bool wino_k4 = true;
+    // The Winograd tower as ONE launch (tower_wino4_kernel) while its grid fits the device, one workgroup per CU (diagnostic switch
+    // CATTUS_WINO_PERSIST=0: per-layer launches; CATTUS_WINO_SPIN=<polls>: the budget of a hand-off wait).  persist_ok falls when
+    // a launch reported a wait that gave up: the batch is run again on the per-layer launches, and so is every later one.
+    bool wino_persist = true;
+    std::atomic<bool> persist_ok{true};
+    uint32_t persist_spin = 1u << 18;
+    uint32_t cus = 0;
     bool wino_inplace = true;      // CATTUS_WINO_INPLACE=0: a third activation buffer for the blocks' outputs (A/B runs)
     bool split_wfrag = true;       // CATTUS_SPLIT_W=0: f16x2 weights through the LDS ring (conv3x3_split_kernel) instead of the register ring
     // tile-forcing switches (CATTUS_CONV_CB, CATTUS_CONV_PBW: A/B runs, the tile-equality tests) and the f16 towers' saturation
@@ -309,6 +322,7 @@ struct cattus_eval {
 
     std::mutex stat_mu;
     cattus_stats stats{};
+    uint64_t stats_tower_fallbacks = 0;  // batches the one-launch tower gave up on (run again on the per-layer launches)
 
     // leaf server
     std::mutex srv_mu;
@@ -348,6 +362,25 @@ size_t blob_floats(const cattus_net_desc& d) {
 // The Winograd kernel this evaluator would run a cin -> cout layer on covers that shape.
 bool wino_shape_ok(const cattus_eval* e, uint32_t cin, uint32_t cout) {
     return e->wino_k4 ? wino4_supported(e->bpad, cin, cout, e->d.board) : wino_supported(e->bpad, cin, cout, e->d.board);
+}
+
+// Launches of the persistent tower never overlap on a device: each waits for the one before it (an event chain per device, process-wide:
+// two evaluators -- model1 and model2 of a self-play round -- or the two lanes of one would otherwise share the CUs, neither launch
+// would have all its workgroups resident, and each would wait for hand-offs from workgroups the other keeps out).  Other work of the
+// lanes (copies, stem, heads) overlaps as before.
+std::mutex g_chain_mu;
+hipEvent_t g_chain[64] = {};
+int chain_persistent_launch(int device, hipStream_t st, const std::function<void()>& launch) {
+    std::lock_guard<std::mutex> lk(g_chain_mu);
+    hipEvent_t& ev = g_chain[device & 63];
+    if (!ev) {
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    } else {
+        HIP_TRY(hipStreamWaitEvent(st, ev, 0));
+    }
+    launch();
+    HIP_TRY(hipEventRecord(ev, st));
+    return CATTUS_OK;
 }
 
 // Upload one folded 3x3 layer in the layout of the selected tower.  On the tuned path output channels are
@@ -671,6 +704,20 @@ int build(cattus_eval* e, const float* p) {
         if ((rc = L.h_planes.alloc(B * d.planes * e->cfg.plane_words * 8))) return rc;
         if ((rc = L.h_policy.alloc(B * d.moves * 4))) return rc;
         if ((rc = L.h_value.alloc(B * 4))) return rc;
+        if (e->tuned && e->act == Act::F16S && e->wino_k4 && e->wino_persist && e->wino_inplace && d.blocks > 0 && e->c1[0]->wu.p) {
+            // the lane's layer table: conv1 of a block a -> t, conv2 t -> a over its own skip rows (the per-layer launches' in-place plan)
+            std::vector<Wino4TowerLayer> tl;
+            for (uint32_t i = 0; i < d.blocks; i++) {
+                tl.push_back(Wino4TowerLayer{L.a.as<float>(), e->c1[i]->wu.p, e->c1[i]->bw.as<float>(), nullptr, L.t.as<float>()});
+                tl.push_back(Wino4TowerLayer{L.t.as<float>(), e->c2[i]->wu.p, e->c2[i]->bw.as<float>(), L.a.as<float>(), L.a.as<float>()});
+            }
+            L.tower_nlayers = (uint32_t)tl.size();
+            if ((rc = L.tower_layers.upload(tl.data(), tl.size() * sizeof(Wino4TowerLayer)))) return rc;
+            if ((rc = L.tower_ready.alloc((size_t)tl.size() * (bp_ / 4) * 4))) return rc;
+            if ((rc = L.tower_err.alloc(4))) return rc;
+            if ((rc = L.h_tower_err.alloc(4))) return rc;
+            *L.h_tower_err.as<unsigned>() = 0;
+        }
     }
     return CATTUS_OK;
 }
@@ -759,6 +806,19 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
                 else if (wino) launch_conv3x3_wino((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
                 else launch_conv3x3_mfma(e->act, in, wptr(c), c.b.as<float>(), res, out, nb, FP, FP, S, st, s0, s1, nullptr, wflag | lflags, e->conv_opts);
             };
+            if (wino && L.tower_nlayers && e->persist_ok.load(std::memory_order_relaxed) && wino4_tower_fits(nb, FP, e->cus)) {
+                // every layer behind the stem in ONE launch: counters and error word zeroed ahead of it on the same stream, the error word
+                // copied to page-locked memory behind it (eval_host reads it when the batch is back; the device entry points at their next call)
+                hipEvent_t s0 = ev(false), s1 = ev(true);
+                HIP_TRY(hipMemsetAsync(L.tower_ready.p, 0, (size_t)L.tower_nlayers * (nb / 4) * 4, st));
+                HIP_TRY(hipMemsetAsync(L.tower_err.p, 0, 4, st));
+                int crc = chain_persistent_launch(e->device, st, [&] {
+                    launch_tower_wino4(L.tower_layers.as<Wino4TowerLayer>(), L.tower_nlayers, L.tower_ready.as<unsigned>(), L.tower_err.as<unsigned>(),
+                                       e->conv_opts.saturated, nb, FP, e->persist_spin, st, s0, s1);
+                });
+                if (crc) return crc;
+                HIP_TRY(hipMemcpyAsync(L.h_tower_err.p, L.tower_err.p, 4, hipMemcpyDeviceToHost, st));
+            } else
             for (uint32_t i = 0; i < d.blocks; i++) {
                 conv(*e->c1[i], a, nullptr, t, 0);
                 if (wino && e->wino_inplace) {
@@ -870,8 +930,6 @@ int eval_host(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy,
         src_planes = L.h_planes.p;
     }
     HIP_TRY(hipMemcpyAsync(L.d_planes.p, src_planes, pbytes, hipMemcpyHostToDevice, L.stream));
-    int rc = enqueue_forward(e, L, L.d_planes.as<uint64_t>(), n, L.d_policy.as<float>(), L.d_value.as<float>(), L.stream);
-    if (rc) return rc;
     auto copy_out = [&]() -> int {
         if (lg) {
             HIP_TRY(hipMemcpyAsync(L.d_legal_idx.p, lg->idx, (size_t)n * lg->stride * 2, hipMemcpyHostToDevice, L.stream));
@@ -886,15 +944,34 @@ int eval_host(cattus_eval* e, const uint64_t* planes, uint32_t n, float* policy,
         HIP_TRY(hipMemcpyAsync(direct ? (void*)value : L.h_value.p, L.d_value.p, (size_t)n * 4, hipMemcpyDeviceToHost, L.stream));
         return CATTUS_OK;
     };
-    if ((rc = copy_out())) return rc;
-    // Wait for the batch.  hipStreamSynchronize spins on the completion signal (lowest latency: +3 % self-play
-    // throughput on a 16-CPU share with 8 search threads); CATTUS_HIP_WAIT=block sleeps on a blocking-sync
-    // event instead, which frees the core each waiting thread would burn (for hosts short of CPUs).
-    if (e->wait_spin) {
-        HIP_TRY(hipStreamSynchronize(L.stream));
-    } else {
-        HIP_TRY(hipEventRecord(L.done, L.stream));
-        HIP_TRY(hipEventSynchronize(L.done));
+    // Forward + copies + wait.  hipStreamSynchronize spins on the completion signal (lowest latency: +3 % self-play throughput on a 16-CPU
+    // share with 8 search threads); CATTUS_HIP_WAIT=block sleeps on a blocking-sync event instead, which frees the core each waiting
+    // thread would burn (for hosts short of CPUs).
+    auto run_batch = [&]() -> int {
+        int rc = enqueue_forward(e, L, L.d_planes.as<uint64_t>(), n, L.d_policy.as<float>(), L.d_value.as<float>(), L.stream);
+        if (rc) return rc;
+        if ((rc = copy_out())) return rc;
+        if (e->wait_spin) {
+            HIP_TRY(hipStreamSynchronize(L.stream));
+        } else {
+            HIP_TRY(hipEventRecord(L.done, L.stream));
+            HIP_TRY(hipEventSynchronize(L.done));
+        }
+        return CATTUS_OK;
+    };
+    int rc = run_batch();
+    if (rc) return rc;
+    if (L.h_tower_err.p && *L.h_tower_err.as<volatile unsigned>() != 0) {
+        // a hand-off wait of the one-launch tower ran out of its budget (its workgroups were not all resident: somebody else's kernels
+        // on this device): the launch finished on rows that were not ready.  Nothing of it is kept: this evaluator goes back to the
+        // per-layer launches, for this batch (again, from the planes) and for every later one.
+        *L.h_tower_err.as<volatile unsigned>() = 0;
+        e->persist_ok.store(false, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> sl(e->stat_mu);
+            e->stats_tower_fallbacks += 1;
+        }
+        if ((rc = run_batch())) return rc;
     }
     if (!direct) {
         if (!lg) memcpy(policy, L.h_policy.p, (size_t)n * d.moves * 4);
@@ -971,7 +1048,7 @@ CATTUS_API const char* cattus_hip_tower_kernel(const cattus_eval* e) {
     if (!e->tuned) return "conv3x3_generic_kernel";
     if (e->tower64) return "tower64_lds_kernel";
     if (e->tower64s) return "tower64_split_kernel";
-    if (e->act == Act::F16S) return e->d.blocks > 0 && e->c1[0]->wu.p ? (e->wino_k4 ? "conv3x3_wino4_kernel" : "conv3x3_wino_kernel") : e->split_wfrag ? "conv3x3_splitw_kernel" : "conv3x3_split_kernel";
+    if (e->act == Act::F16S) return e->d.blocks > 0 && e->c1[0]->wu.p ? (e->wino_k4 ? (e->lanes[0].tower_nlayers && e->persist_ok.load() && wino4_tower_fits(e->bpad, e->fpad, e->cus) ? "tower_wino4_kernel" : "conv3x3_wino4_kernel") : "conv3x3_wino_kernel") : e->split_wfrag ? "conv3x3_splitw_kernel" : "conv3x3_split_kernel";
     return "conv3x3_mfma_v2_kernel";
 }
 
@@ -985,7 +1062,7 @@ struct Switches {
         if (!text) return CATTUS_OK;
         static const char* const known[] = {"CATTUS_CONV_CB", "CATTUS_CONV_PBW", "CATTUS_FUSED_STEM", "CATTUS_T64_CH", "CATTUS_T64_LS", "CATTUS_SPLIT_W",
                                             "CATTUS_T64S_HEADS", "CATTUS_T64S_SHAPE", "CATTUS_TOWER64", "CATTUS_FORCE_GENERIC", "CATTUS_WINO_INPLACE",
-                                            "CATTUS_ARENA", "CATTUS_WINO_KERNEL"};
+                                            "CATTUS_ARENA", "CATTUS_WINO_KERNEL", "CATTUS_WINO_PERSIST", "CATTUS_WINO_SPIN"};
         const std::string s(text);
         size_t at = 0;
         while (at < s.size()) {
@@ -1138,6 +1215,15 @@ int create_impl(const void* weights, size_t nbytes, const cattus_eval_config* cf
         if (wk && strcmp(wk, "k16") != 0 && strcmp(wk, "k4") != 0) return fail(CATTUS_E_INVALID, "CATTUS_WINO_KERNEL is k16 or k4");
         e->wino_k4 = wk ? strcmp(wk, "k4") == 0 : wino4_supported(e->bpad, e->fpad, e->fpad, d.board);
     }
+    {
+        const char* wp = sw.get("CATTUS_WINO_PERSIST");
+        e->wino_persist = !(wp && wp[0] == '0');
+        const char* ws = sw.get("CATTUS_WINO_SPIN");
+        if (ws) e->persist_spin = (uint32_t)std::max(1L, atol(ws));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+        e->cus = (uint32_t)prop.multiProcessorCount;
+    }
     if (cfg->tower_form == CATTUS_TOWER_WINOGRAD && !(e->tuned && e->act == Act::F16S && d.blocks > 0 && wino_shape_ok(e.get(), e->fpad, e->fpad)))
         return fail(CATTUS_E_UNSUPPORTED, "tower_form WINOGRAD needs dtype f16x2, an 8x8 board, at least one residual block and a multiple of 64 filters");
     if (e->tuned && e->act == Act::F16S && e->winograd && d.blocks > 0 && wino_shape_ok(e.get(), e->fpad, e->fpad) &&
@@ -1216,6 +1302,13 @@ CATTUS_API int cattus_hip_eval_device_lane(cattus_eval* e, uint32_t lane, const 
     Lane& L = e->lanes[lane];
     std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
+    if (L.h_tower_err.p && *L.h_tower_err.as<volatile unsigned>() != 0) {
+        // this entry point is asynchronous: what an earlier call's one-launch tower reported is seen here, at the next call
+        *L.h_tower_err.as<volatile unsigned>() = 0;
+        e->persist_ok.store(false, std::memory_order_relaxed);
+        return fail(CATTUS_E_DEVICE, "an earlier batch on lane %u ran the tower as one launch and a hand-off wait in it gave up (the device was shared): that batch's "
+                                     "outputs are invalid; this evaluator uses the per-layer launches from now on", lane);
+    }
     hipStream_t st = (hipStream_t)stream;  // as HIP itself: NULL is the legacy default stream, not a private one
     int rc = enqueue_forward(e, L, d_planes, n, d_policy, d_value, st);
     if (rc) return rc;
@@ -1359,6 +1452,8 @@ CATTUS_API int cattus_hip_time_tower(cattus_eval* e, uint32_t n, uint32_t reps, 
     Lane& L = e->lanes[0];
     std::lock_guard<std::mutex> lk(L.mu);
     HIP_TRY(hipSetDevice(e->device));
+    // (the one-launch Winograd tower is reported per LAYER: its duration + the stem's over 1 + 2 blocks, so that a caller's
+    // flops-per-launch arithmetic does not change with how the layers are launched)
     const uint32_t per_fwd = e->tower64 || e->tower64s ? 1 : 1 + 2 * e->d.blocks;
     TowerTimer tt;
     tt.ev.resize((size_t)2 * per_fwd);

@@ -262,6 +262,7 @@ SP_API int cattus_sp_run(int game, const cattus_sp_config* c, cattus_net_eval_fn
         s.run_duration = m.run_duration_ema, s.search_duration = m.search_duration_ema;
         s.seconds = r.seconds;
         s.steady_seconds = r.steady_seconds, s.steady_node_evals = r.steady_node_evals;
+        s.steady_plies = r.steady_plies, s.steady_batches = r.steady_batches;
         s.adjudicated = r.adjudicated;
         res->record_bytes = Serializer<G>::RECORD_BYTES;
         if (!keep_records) res->records.clear();

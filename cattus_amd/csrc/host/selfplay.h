@@ -52,6 +52,7 @@ struct Metrics {
     alignas(64) std::atomic<uint64_t> cache_misses{0};
     alignas(64) std::atomic<uint64_t> activation_count{0};
     std::atomic<uint64_t> node_evals{0};
+    std::atomic<uint64_t> plies{0};  // moves played (a game's records are counted in `positions` only when it ends)
     double run_duration_ema = 0.0, search_duration_ema = 0.0;  // RunningAverage eps 0.99 (util/metric.rs)
     std::mutex mu;
     void set_run(double s) {
@@ -350,6 +351,7 @@ struct SelfPlayResult {
     // when the last games finish and batches can no longer be filled)
     double steady_seconds = 0;
     uint64_t steady_node_evals = 0;
+    uint64_t steady_plies = 0, steady_batches = 0;  // moves played and batches run in that window
     uint64_t adjudicated = 0;  // games cut at max_game_plies
 };
 
@@ -518,6 +520,7 @@ class SelfPlayRunner {
                 if (res.steady_seconds == 0 && (uint64_t)(nslots - done) * 4 < (uint64_t)nslots * 3) {
                     res.steady_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     res.steady_node_evals = metrics_.node_evals;
+                    res.steady_plies = metrics_.plies, res.steady_batches = metrics_.activation_count;
                 }
                 if (pending[0].size() >= cfg_.batch_size || pending[1].size() >= cfg_.batch_size) wake = true;
                 if (ready.empty() && busy == 0) wake = true;
@@ -622,7 +625,9 @@ class SelfPlayRunner {
         for (auto& s : slots)
             if (!s.error.empty()) error_ = s.error, frc = -2;
         res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (res.steady_seconds == 0) res.steady_seconds = res.seconds, res.steady_node_evals = metrics_.node_evals;
+        if (res.steady_seconds == 0)
+            res.steady_seconds = res.seconds, res.steady_node_evals = metrics_.node_evals, res.steady_plies = metrics_.plies,
+            res.steady_batches = metrics_.activation_count;
         return frc;
     }
 
@@ -743,6 +748,7 @@ class SelfPlayRunner {
                         }
                         s.pairs.emplace_back(s.game.history.back(), std::move(probs));
                         s.game.play(m);
+                        metrics_.plies.fetch_add(1, std::memory_order_relaxed);
                         s.state = Slot::NEXT_MOVE;
                     }
                     break;

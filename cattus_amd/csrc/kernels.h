@@ -105,6 +105,20 @@ bool wino4_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S);
 void launch_conv3x3_wino4(const float* in, const void* wu, const float* bias, const float* res, float* out, uint32_t bpad, uint32_t cin,
                           uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat);
 hipError_t prepare_wino4();
+// The whole Winograd tower in one launch (tower_wino4_kernel): a table of its layers in device memory (an even number: residual blocks,
+// the first layer of a block without skip rows, the second with; res may equal out), `ready` = nlayers x (bpad / 4) zeroed counters, `err` a zeroed word the launch sets when a hand-off wait ran out of
+// `spin_budget` polls (the outputs are then invalid: run the batch on the per-layer launches).  Only while wino4_tower_fits: every
+// workgroup resident at once (one per CU), and never two such launches on one device at a time.
+struct Wino4TowerLayer {
+    const float* in;
+    const void* wu;
+    const float* bias;
+    const float* res;
+    float* out;
+};
+bool wino4_tower_fits(uint32_t bpad, uint32_t filters, uint32_t cus);
+void launch_tower_wino4(const Wino4TowerLayer* d_layers, uint32_t nlayers, unsigned* ready, unsigned* err, unsigned* sat, uint32_t bpad, uint32_t filters,
+                        uint32_t spin_budget, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // Diagnostic: one launch of nothing but back-to-back MFMAs of the tower's kind (F16S: f16, BF16, F32: 32x32x2 f32), four
 // waves on each of `cus` workgroups, iters x 4 MFMAs per wave; `out` holds cus * 256 floats.  Returns the launch's FLOPs.

@@ -27,15 +27,6 @@
 //       in K1w's order, * 2^-s + bias, + skip, ReLU, cap, whole-line f32 stores.
 // Per accumulator the MFMA sequence is K1w's (k ascending; U_lo V_hi, U_hi V_lo, U_hi V_hi), V and Y are combined in K1w's order:
 // the two kernels agree BIT FOR BIT (tests/test_hip_parity.py::test_winograd_kernels_agree_bit_for_bit).
-//
-// Where its time goes (round 5, scripts/stamps_w4.py and scripts/probes/w4_variant.py, profiles/r05_w4_anatomy.txt; chess 256 -> 256,
-// batch 256, cycles per wave at 1.85-1.93 GHz): prologue 6.3-7.1 k (first chunk from memory, V of k-step 0), loop 40.9-41.6 k,
-// ring drain 1.6 k, Z exchange 3.5 k, Y + stores 2.5 k.  The loop's floor is 24.6 k (768 MFMAs x 32); with the transform, the U ring and
-// the DMA taken out it runs in 26.3 k, and each of them adds what it costs when put back alone (transform 7.1 k, ring 4.0 k, DMA 5.0 k):
-// with ONE wave per SIMD nothing issues in an MFMA's shadow beyond ~24 cycles per gap, and a k-step carries ~350 instructions besides
-// its 48 MFMAs.  Without its MFMAs the loop still takes 32.6 k.  A second wave per SIMD is what would hide that stream, and 256
-// accumulator registers per wave rule it out (the designs with 128 were sized in DESIGN.md K1w4: none fits 256 registers with V in
-// registers, and V through LDS is LDS-bound).
 #include "kernels.h"
 #include "device_common.h"
 
@@ -53,17 +44,6 @@ constexpr int W4_LDS_Z = 4 * 2 * 64 * 256;    // the epilogue's exchange: [wave]
 constexpr int W4_LDS_TOTAL = W4_LDS_Z > W4_LDS_LOOP ? W4_LDS_Z : W4_LDS_LOOP;
 static_assert(W4_IMG % 256 == 0 && W4_IMGZ % 256 == 0 && W4_DBUF % 256 == 0, "the zero area keeps a read's banks only if everything is 256-B aligned");
 
-constexpr int W4_P = 5;  // LDS-DMA pieces per wave and image: 4 x 5 = 20 >= the image's 19 KiB pieces
-
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"  // "clobber list contains reserved registers: m0": intended, see below
-__device__ __forceinline__ void w4_glds16(const char* gsrc, uint32_t lds_dst) {
-    // LDS-DMA of 64 x 16 bytes, hidden from the compiler (kernels_wino.hip); M0 = the wave-uniform LDS byte address, declared clobbered
-    // (nothing else in this kernel lives in M0: no save / restore around each of the 10 pieces per chunk)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
-}
-#pragma clang diagnostic pop
-
 typedef __attribute__((ext_vector_type(2))) _Float16 w4_f16x2;
 
 template <int V>
@@ -79,20 +59,37 @@ __device__ unsigned long long g_stamps_w4[1024 * 4 * 8];
 #define W4_STAMP_RT(i)
 #endif
 
-template <bool HAS_RES>
-__global__ void __launch_bounds__(256, 1)
-    conv3x3_wino4_kernel(const float* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
-                         const float* res, float* out, unsigned* __restrict__ sat, int cin, int cout) {
+// What a workgroup of the PERSISTENT tower (tower_wino4_kernel below) knows besides the layer: where its board group's producers of
+// the previous layer count themselves, and where it counts itself when its rows are written.
+struct W4Sync {
+    const unsigned* wait_word;  // ready[layer - 1][board group] (null: the layer's input was complete before the launch)
+    unsigned* done_word;        // ready[layer][board group]
+    unsigned* err;              // the launch's error word: set by a workgroup whose wait ran out of its budget
+    unsigned wait_target;       // producers per board group: the cout groups
+    unsigned spin_budget;       // polls (with s_sleep) before a wait gives up
+};
+
+// One layer on one workgroup.  RES: 0 = no skip rows, 1 = skip rows.
+// PERSIST: called layer after layer from tower_wino4_kernel -- the activation loads and skip loads carry sc1 (they read what other CUs
+// wrote during this launch: past this CU's L1), the stores carry sc1 (written through), and the workgroup waits for its board
+// group's producers before its first activation load and counts itself in behind its last store.
+template <int RES, bool PERSIST>
+__device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
+                                         const float* res, float* out, unsigned* __restrict__ sat, int cin, int cout, char* smem,
+                                         const W4Sync& sync) {
     typedef _Float16 T;
     typedef Mfma<T>::frag frag;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool has_res = RES == 1;
 
 #ifdef CATTUS_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     W4_STAMP(0);
     W4_STAMP_RT(6);
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    // (an opaque copy: in the tower kernel everything derived from the thread index would otherwise be hoisted out of the layer loop
+    // and stay live through all of it -- some 40 registers the loop does not have)
+    asm volatile("" : "+v"(tid));
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave = the frequency row it owns
     const int lane = tid & 63;
 
@@ -128,37 +125,66 @@ __global__ void __launch_bounds__(256, 1)
         slot[0] = a, slot[1] = b, slot[2] = c, slot[3] = d;
     };
 
-    // ---- LDS-DMA of a chunk: per tile block an image of 16 board rows x 76 sixteen-byte pieces (8 pixels of 9 pieces: eight of
-    // data, the ninth re-reads the eighth; 4 pieces of padding that re-read too); the second board of an image sits one piece to
-    // the right.  1,216 pieces = 19 instructions of 64 per image; a wave issues 5 of each image (the 20th repeats the 19th) ----
+    // ---- activation chunks: global -> registers -> LDS.  (LDS-DMA first: 10 pieces of 1 KiB per wave and chunk cost the issuing wave
+    // ~60 cycles each, 5,000 of the loop's 41,000 cycles -- a global_load_dwordx4 + ds_write_b128 pair costs a third of that, moves no
+    // padding and needs no per-lane offset table.)  A chunk = 256 pixel rows x 128 B = 2,048 sixteen-byte pieces, 8 per thread: piece
+    // i of thread t = pixel row 32 i + (t >> 3), piece t & 7 -- a wave instruction reads eight whole 128-byte rows.  Image layout per
+    // tile block as in K1w: pixel pitch 144 B, board rows of 8 pixels + 64 B, the second board one 16-B piece to the right, zero area behind.
     const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
-    uint32_t off_a[W4_P];
-#pragma unroll
-    for (int i = 0; i < W4_P; i++) {
-        const int id = min(q * W4_P + i, 18);
-        const int sidx = id * 64 + lane, brow = sidx / 76, w = sidx - brow * 76, wsh = max(w - (brow >> 3), 0);
-        const int x = min(wsh / 9, 7), c = min(wsh - (wsh / 9) * 9, 7);
-        off_a[i] = (uint32_t)(brow * 8 + x) * row_bytes + c * 16;
-    }
-    const uint32_t dst_a0 = (uint32_t)min(q * W4_P, 18) * 1024;  // a wave's pieces are consecutive (the last wave's run stops at 18)
-    auto issue_chunk = [&](int ch, uint32_t dbuf) __attribute__((always_inline)) {  // chunk ch -> the buffer at dbuf
+    const uint32_t aoff = (uint32_t)(tid >> 3) * row_bytes + (tid & 7) * 16;
+    const uint32_t wdst = (uint32_t)(q * W4_RP + ((tid >> 3) & 7) * SP + (tid & 7) * 16);  // pixel row 32 i + (t >> 3) = board row 4 i + q, column (t >> 3) & 7
+    constexpr int W4_NP = 8;  // loads per thread and chunk: they count in vmcnt like the ring's
+    auto load_chunk = [&](u32x4(&regs)[W4_NP], int ch) __attribute__((always_inline)) {
         const char* src = abase0 + (size_t)ch * 128;
 #pragma unroll
-        for (int tb = 0; tb < 2; tb++)
-#pragma unroll
-            for (int i = 0; i < W4_P; i++) {
-                const uint32_t dst = dbuf + tb * W4_IMGZ + min(dst_a0 + i * 1024u, 18u * 1024u);
-                w4_glds16(src + (size_t)tb * 128 * row_bytes + off_a[i], dst);
-            }
+        for (int i = 0; i < W4_NP; i++) {
+            u32x4 r;
+            if (PERSIST) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(r) : "v"(aoff), "s"(src + (size_t)i * 32 * row_bytes) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(aoff), "s"(src + (size_t)i * 32 * row_bytes) : "memory");
+            regs[i] = r;
+        }
+    };
+    auto store_piece = [&](const u32x4(&regs)[W4_NP], uint32_t dbuf_plus_wdst, int i) __attribute__((always_inline)) {
+        // board row 4 i + q of the workgroup's 32: tile block i >> 2, board (i >> 1) & 1 of it, row 4 (i & 1) + q of that board
+        const int imm = (i >> 2) * W4_IMGZ + ((i & 3) * 4) * W4_RP + ((i >> 1) & 1) * 16;
+        *reinterpret_cast<u32x4*>(smem + dbuf_plus_wdst + imm) = regs[i];
     };
     for (int i = tid; i < 4 * (W4_ZAREA / 16); i += 256)  // the four zero areas
         reinterpret_cast<f32x4*>(smem + (i / (W4_ZAREA / 16)) * W4_IMGZ + W4_IMG)[i % (W4_ZAREA / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // both first chunks go out ahead of the ring: every ring load is then younger than every DMA, as in the steady state
-    issue_chunk(0, 0);
-    issue_chunk(1, W4_DBUF);  // cin >= 128: at least four chunks
+    // The ring's l = 0, 1 first -- the weights do not depend on anybody --, then (PERSIST) the wait for the board group's producers of the
+    // previous layer, then chunk 0, chunk 1 and the ring's l = 2, 3: the order of the steady state, where a chunk goes out in stage 4 of
+    // the odd k-step between the refills of l = 0, 1 and of l = 2, 3 -- the counted waits of k-step 0 are then those of every even k-step
+    // (scripts/audit_inflight_regs.py caught the one order in which they were not).  `pend` holds the chunk on its way throughout the
+    // loop: written to the freed buffer in stage 4 of the even k-step
+    u32x4 first[W4_NP], pend[W4_NP];
     const char* wks = wb0;  // U of the k-step being multiplied
-#pragma unroll
-    for (int l = 0; l < 4; l++) load_ustage(ring[l], wks, l);
+    load_ustage(ring[0], wks, 0);
+    load_ustage(ring[1], wks, 1);
+    if (PERSIST && sync.wait_word) {
+        // one lane polls (sc1: past this CU's L1) until every cout group of this board group has counted itself in for the previous
+        // layer, with a budget.  A wait that runs out raises the launch's error word AND GOES ON -- on rows that are not ready: the
+        // launch then finishes at once instead of timing out workgroup after workgroup, every address it touches is its own, and the
+        // host, which reads the error word behind every launch, throws the batch's outputs away and runs it on the per-layer launches.
+        // A raised error word ends every other wait too.  The barrier stands between the poll and every load of the rows.
+        if (tid == 0) {
+            unsigned budget = sync.spin_budget, seen = 0, bad = 0;
+            for (;;) {
+                asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(sync.wait_word) : "memory");
+                if (seen >= sync.wait_target) break;
+                if ((budget & 63) == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(bad) : "v"(sync.err) : "memory");
+                if (bad != 0 || --budget == 0) {
+                    atomicExch(sync.err, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");
+    }
+    load_chunk(first, 0);
+    load_chunk(pend, 1);  // cin >= 128: at least four chunks
+    load_ustage(ring[2], wks, 2);
+    load_ustage(ring[3], wks, 3);
 
     // ---- the transform's geometry: lane = (tile n of the tile block, k-half hh): board n >> 4, tile row (n >> 2) & 3, column n & 3 ----
     // Wave q combines the patch rows (ra, rb) of its tile: q = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 (B^T row q), as
@@ -257,9 +283,14 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[l][t2][c][e] = 0.0f;
 
-    // ---- prologue: chunk 0 has landed (everything but the ring's 16 loads and chunk 1's 10 pieces); the rows of the first group, phase
-    // (0, tb0) whole, the first half of phase (0, tb1) -- its second half sits in stages 0, 1 of k-step 0, where every later k-step has it ----
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(16 + 2 * W4_P) : "memory");
+    // ---- prologue: chunk 0 has landed (everything but chunk 1's 8 loads and the ring's last 8) and goes to buffer 0; the rows of the first
+    // group, phase (0, tb0) whole, the first half of phase (0, tb1) -- its second half sits in stages 0, 1 of k-step 0, as in every k-step ----
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(first[0]), "+v"(first[1]), "+v"(first[2]), "+v"(first[3]), "+v"(first[4]), "+v"(first[5]), "+v"(first[6]), "+v"(first[7])
+                 : "n"(W4_NP + 8));  // all but chunk 1 and the ring's l = 2, 3
+#pragma unroll
+    for (int i = 0; i < W4_NP; i++) store_piece(first, wdst, i);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     read_row(pa, 0, 0, 0, 0);
     read_row(pb, 1, 0, 0, 0);
 #pragma unroll
@@ -269,39 +300,51 @@ __global__ void __launch_bounds__(256, 1)
 
     // One k-step: 8 stages of 6 MFMAs; SP_ = parity of the k-step (compile time), which fixes the l = 2,3 set, the chunk half the
     // slices read and the wait counts.  `wnext`: U of the next k-step (clamped to the last: nobody uses those refills).
-    auto kstep = [&](const char* wnext, int ch_next, auto sp_tag) __attribute__((always_inline)) {
+    // LAST: the layer's last k-step -- nothing left to fetch, refill or transform, no chunk change.
+    auto kstep = [&](const char* wnext, int ch_next, auto sp_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr int SP_ = decltype(sp_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value != 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             // stage i: (tb, l) in the order (0,0) (0,1) (1,0) (1,1) (0,2) (0,3) (1,2) (1,3)
             const int tbv = (i >> 1) & 1, l = (i & 1) + ((i >> 2) << 1);
             const bool first_use = tbv == 0;
-            if (i == 0 && SP_ == 1) {
+            if (i == 0 && SP_ == 1 && !LAST) {
                 // the chunk change, at the start of the odd k-step: every LDS read issued during k-step s feeds V of k-step s + 1, so chunk c
                 // was last read in the even k-step; every wave has seen its own pieces of chunk c + 1 land (they are older than ring loads
                 // waited for since).  Behind the barrier chunk c + 1 is everybody's and chunk c's buffer takes chunk c + 2
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                const uint32_t freed = (uint32_t)(bufstep > 0 ? 0 : W4_DBUF);  // the buffer cur[] pointed into until now
 #pragma unroll
                 for (int X = 0; X < 2; X++)
 #pragma unroll
                     for (int k = 0; k < 3; k++) cur[X][k] += bufstep;
                 bufstep = -bufstep;
-                issue_chunk(ch_next, freed);
+            }
+            if (i == 4 && SP_ == 1 && !LAST) {
+                // chunk c + 2 into registers, BEHIND the refills of l = 0, 1: loads complete in order, these come from far away (the
+                // previous layer's non-temporal stores), and the first ring stage that has to wait for them is l = 2 of the next
+                // k-step, nine stages from here (issued at the chunk change it was l = 0, six stages away: ~600 cycles stalled per chunk)
+                load_chunk(pend, ch_next);
             }
             if (first_use) {
-                // younger than this U stage: the refills of the slots freed since (l = 0: l = 1, 2, 3 of this k-step; l = 1: 2, 3; l = 2: 3 and the
-                // next k-step's 0, 1; l = 3: those two) -- and, in the odd k-step, the chunk's 2 W4_P pieces issued at its start
-                constexpr int DMA = 2 * W4_P;
+                constexpr int NP = W4_NP;
                 u32x4 r0 = ring[l][0], r1 = ring[l][1], r2 = ring[l][2], r3 = ring[l][3];
-                if (l == 0 && SP_ == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-                else if (l == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + DMA));
-                else if (l == 1 && SP_ == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-                else if (l == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + DMA));
-                else if (l == 2 && SP_ == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-                else if (l == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + DMA));
+                // younger than this U stage: the refills of the slots freed since (l = 0: l = 1, 2, 3 of this k-step; l = 1: 2, 3; l = 2: 3 and the
+                // next k-step's 0, 1; l = 3: those two) and the chunk's W4_NP loads where they went out in between (odd k-step, stage 4:
+                // behind the next k-step's l = 0, 1, ahead of its 2, 3)
+                if (l == 0 && SP_ == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + NP));
+                else if (l == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                else if (l == 1 && SP_ == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + NP));
+                else if (l == 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                else if (l == 2 && SP_ == 0) {
+                    // the even k-step's l = 2 is the first stage younger than the chunk loaded in the odd k-step before: its registers are
+                    // operands of this wait, and the stores into the freed buffer follow it (this stage's gaps)
+                    asm volatile("s_waitcnt vmcnt(12)"
+                                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(pend[0]), "+v"(pend[1]), "+v"(pend[2]), "+v"(pend[3]), "+v"(pend[4]),
+                                   "+v"(pend[5]), "+v"(pend[6]), "+v"(pend[7]));
+                } else if (l == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + NP));
                 else if (SP_ == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-                else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + DMA));
+                else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + NP));
                 ring[l][0] = r0, ring[l][1] = r1, ring[l][2] = r2, ring[l][3] = r3;
             }
             const frag uh0 = __builtin_bit_cast(frag, ring[l][0]), ul0 = __builtin_bit_cast(frag, ring[l][1]);
@@ -314,6 +357,12 @@ __global__ void __launch_bounds__(256, 1)
                 const int ph = (gp + e) / 24, j = (gp + e) % 24;  // ph = 1: (s, tb1); 2: (s + 1, tb0); 3: (s + 1, tb1)
                 __builtin_amdgcn_sched_barrier(0);
                 slot(ph == 1 ? SP_ : SP_ ^ 1, ph == 2 ? 0 : 1, j);
+                // stage 4 of the even k-step: the pending chunk into the buffer the last chunk change left (two pieces per gap)
+                if (SP_ == 0 && i == 4 && e < 4) {
+                    const uint32_t target = wdst + (uint32_t)(bufstep > 0 ? W4_DBUF : 0);
+                    store_piece(pend, target, 2 * e);
+                    store_piece(pend, target, 2 * e + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             };
             Mfma<T>::mac(ul0, vh, acc[l][tbv][0]);
@@ -328,24 +377,27 @@ __global__ void __launch_bounds__(256, 1)
             gap(4);
             Mfma<T>::mac(uh1, vh, acc[l][tbv][1]);
             gap(5);
-            if (!first_use) load_ustage(ring[l], wnext, l);  // the slot is free: the next k-step's stage
+            if (!first_use && !LAST) load_ustage(ring[l], wnext, l);  // the slot is free: the next k-step's stage
         }
     };
     W4_STAMP(1);
-    for (int c = 0; c < nch; c++) {
+    int c = 0;
+    do {  // (a loop the compiler knows to run at least once: guarded, it keeps the prologue's V and ring values alive across it for the
+          // path that skips it -- 32 registers, spilled in the tower kernel)
         const char* w1 = wks + (size_t)16 * SW_STAGE;                       // k-step 2c + 1
         const char* w2 = wks + (size_t)(c + 1 < nch ? 32 : 16) * SW_STAGE;  // k-step 2c + 2, or the last one again
-        kstep(w1, 0, w4_int<0>{});
-        kstep(w2, min(c + 2, nch - 1), w4_int<1>{});  // the chunk change inside fetches chunk c + 2 (or the last one again: nobody reads it)
+        kstep(w1, 0, w4_int<0>{}, w4_int<0>{});
+        kstep(w2, min(c + 2, nch - 1), w4_int<1>{}, w4_int<0>{});  // the chunk change inside fetches chunk c + 2 (or the last one again: nobody reads it)
         wks = w2;
-    }
+    } while (++c < nch);
     W4_STAMP(2);
-    // the ring's last refills and the last DMA (nobody uses them: the loop's wait counts are the same in every k-step); the ring's registers
-    // are operands of the wait (kernels_wino.hip: to the compiler they are free from their last MFMA on, and it would park epilogue values
-    // in them while the loads are still on their way)
+    // the ring's last refills and the last chunk (nobody uses them: the loop's wait counts are the same in every k-step); the ring's and the
+    // pending chunk's registers are operands of the wait (kernels_wino.hip: to the compiler they are free from their last use on, and it
+    // would park epilogue values in them while the loads are still on their way)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int l = 0; l < 4; l++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[l][0]), "+v"(ring[l][1]), "+v"(ring[l][2]), "+v"(ring[l][3])::"memory");
+    asm volatile("" : "+v"(pend[0]), "+v"(pend[1]), "+v"(pend[2]), "+v"(pend[3]), "+v"(pend[4]), "+v"(pend[5]), "+v"(pend[6]), "+v"(pend[7]));
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue ----
@@ -358,9 +410,13 @@ __global__ void __launch_bounds__(256, 1)
     // wave q finishes tile row q of every board: pixel q * 16 + k of a board for k = 0..15 (y = 2 q + (k >> 3), x = k & 7)
     const size_t orow = (size_t)row0 + board * 64 + q * 16;
     f32x4 skip[16];
-    if (HAS_RES) {
+    if (has_res) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) skip[k] = *reinterpret_cast<const f32x4*>(res + (orow + k) * (size_t)cout + cout0 + pc * 4);
+        for (int k = 0; k < 16; k++) {
+            const float* sp = res + (orow + k) * (size_t)cout + cout0 + pc * 4;
+            if (PERSIST) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(skip[k]) : "v"(sp) : "memory");
+            else skip[k] = *reinterpret_cast<const f32x4*>(sp);
+        }
     }
     W4_STAMP(3);
     asm volatile("s_barrier" ::: "memory");  // every wave has left the chunk buffers (no LDS read of the loop is outstanding: they fed VALU work long done)
@@ -385,6 +441,11 @@ __global__ void __launch_bounds__(256, 1)
                 *reinterpret_cast<f32x4*>(zp + 64 * 256) = z1;
             }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (PERSIST && has_res) {  // the asm skip loads (the compiler does not count them)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(skip[0]), "+v"(skip[1]), "+v"(skip[2]), "+v"(skip[3]), "+v"(skip[4]), "+v"(skip[5]), "+v"(skip[6]), "+v"(skip[7]), "+v"(skip[8]),
+                       "+v"(skip[9]), "+v"(skip[10]), "+v"(skip[11]), "+v"(skip[12]), "+v"(skip[13]), "+v"(skip[14]), "+v"(skip[15]));
+    }
     W4_STAMP(4);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -399,16 +460,29 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float x = __builtin_fmaf(a[j], ds4[j], bias4[j]);  // the inverse weight scale is a power of two: the fma rounds once
-            if (HAS_RES) x = x + skip[k][j];
+            if (has_res) x = x + skip[k][j];
             x = x > 0.0f ? x : 0.0f;
             v[j] = x < WINO_ACT_MAX ? x : WINO_ACT_MAX;  // the next layer's transform relies on it
         }
         vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-        // plain stores: the rows are read again by the four cout-group workgroups of this board group in the next layer, which run on
-        // this XCD (the block-index map above) -- left in its L2 they cost 0.4 us per launch less than non-temporal ones (K1w: the reverse)
-        *reinterpret_cast<f32x4*>(out + (orow + k) * (size_t)cout + cout0 + pc * 4) = v;
+        float* op = out + (orow + k) * (size_t)cout + cout0 + pc * 4;
+        // PERSIST: written through (sc1), every 128-byte line whole by this one instruction -- what the next layer's sc1 loads on other CUs
+        // may read once this workgroup has counted itself in.  Else plain stores: the rows are read again by the four cout-group workgroups
+        // of this board group in the next launch, which run on this XCD (the block-index map) -- left in its L2 they cost 0.4 us per launch
+        // less than non-temporal ones (K1w: the reverse)
+        // (the s_nop: a store of more than 8 bytes reads its data registers a cycle or two after it issues, and gfx940 wants two wait
+        // states before a VALU instruction overwrites them -- the compiler pads its own stores, it cannot see into this one: without it
+        // the next pixel's values, computed into the same registers, went out with this pixel's address)
+        if (PERSIST) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(op), "v"(v) : "memory");
+        else *reinterpret_cast<f32x4*>(op) = v;
     }
     if (vmax >= WINO_ACT_MAX) atomicAdd(sat, 1u);  // an activation reached the cap somewhere in this thread's share
+    if (PERSIST) {
+        // every storing wave drains its stores, the workgroup meets, ONE lane counts the workgroup in (agent scope): the order the
+        // guide's hand-off table was measured in.  The barrier also keeps the next layer's LDS writes behind this layer's last LDS reads
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid == 0) __hip_atomic_fetch_add(sync.done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef CATTUS_STAMPS
     W4_STAMP(5);
     W4_STAMP_RT(7);
@@ -419,11 +493,48 @@ __global__ void __launch_bounds__(256, 1)
 #endif
 }
 
-#ifdef CATTUS_STAMPS
-extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps_w4(unsigned long long* out, size_t n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_w4), n * sizeof(unsigned long long));
+template <bool HAS_RES>
+__global__ void __launch_bounds__(256, 1)
+    conv3x3_wino4_kernel(const float* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
+                         const float* res, float* out, unsigned* __restrict__ sat, int cin, int cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const W4Sync none{};
+    w4_layer<HAS_RES ? 1 : 0, false>(in, wu, bias, res, out, sat, cin, cout, smem, none);
 }
-#endif
+
+// ---- the whole Winograd tower in ONE launch (round 5; the review's "persistent tower") ----
+// grid = one workgroup per (board group, cout group), all resident (one per CU: the evaluator uses it only while the grid fits the
+// device and serialises such launches per device); a workgroup keeps its tile through all layers.  Its only dependency is on the
+// other cout groups of its own board group -- their outputs are its next input -- so the hand-off is a counter per (layer, board
+// group): a workgroup counts itself in behind its last (sc1) store and waits for the count to reach the number of cout groups
+// before its first activation load of the next layer; the ring's first U stages go out BEFORE that wait.  Board groups drift apart:
+// no chip-wide moment at which every workgroup reads its first operands or writes its tile.  Every wait has a budget
+// (W4Sync::spin_budget); a launch one of whose waits ran out says so in `err` (and finishes at once, on garbage) and the host runs
+// the batch again on the per-layer launches.
+__global__ void __launch_bounds__(256, 1)
+    tower_wino4_kernel(const Wino4TowerLayer* __restrict__ layers, int nlayers, unsigned* ready, unsigned* err, unsigned* __restrict__ sat, int filters,
+                       unsigned spin_budget) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblk = gridDim.x, ncg = filters >> 6, ngroups = nblk / ncg;
+    int logical = blockIdx.x;
+    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);  // the map of w4_layer
+    const int group = logical / ncg;
+    // a residual block = two layers: the first without skip rows, the second with (two instantiations of the layer: decided at run time,
+    // the skip registers' undefined values on the path without them cost 32 spilled registers)
+    auto sync_of = [&](int layer) {
+        W4Sync sync;
+        sync.wait_word = layer > 0 ? ready + (size_t)(layer - 1) * ngroups + group : nullptr;
+        sync.done_word = ready + (size_t)layer * ngroups + group;
+        sync.err = err, sync.wait_target = (unsigned)ncg, sync.spin_budget = spin_budget;
+        return sync;
+    };
+    for (int layer = 0; layer + 1 < nlayers; layer += 2) {
+        const Wino4TowerLayer A = layers[layer];
+        w4_layer<0, true>(A.in, reinterpret_cast<const _Float16*>(A.wu), A.bias, nullptr, A.out, sat, filters, filters, smem, sync_of(layer));
+        const Wino4TowerLayer B = layers[layer + 1];
+        w4_layer<1, true>(B.in, reinterpret_cast<const _Float16*>(B.wu), B.bias, B.res, B.out, sat, filters, filters, smem, sync_of(layer + 1));
+    }
+}
 
 bool wino4_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S) {
     return S == 8 && cin >= 128 && cin % 32 == 0 && cout >= 128 && cout % 64 == 0 && bpad % 4 == 0;  // 64 filters: the resident tower
@@ -441,10 +552,28 @@ void launch_conv3x3_wino4(const float* in, const void* wu, const float* bias, co
                               sat, (int)cin, (int)cout);
 }
 
+bool wino4_tower_fits(uint32_t bpad, uint32_t filters, uint32_t cus) {
+    return (bpad / 4) * (filters / 64) <= cus;  // one workgroup per CU, all resident: what the hand-off counters rely on
+}
+
+void launch_tower_wino4(const Wino4TowerLayer* d_layers, uint32_t nlayers, unsigned* ready, unsigned* err, unsigned* sat, uint32_t bpad, uint32_t filters,
+                        uint32_t spin_budget, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const dim3 grid((bpad / 4) * (filters / 64));
+    hipExtLaunchKernelGGL(tower_wino4_kernel, grid, dim3(256), W4_LDS_TOTAL, st, ev_start, ev_stop, 0, d_layers, (int)nlayers, ready, err, sat, (int)filters,
+                          spin_budget);
+}
+
+#ifdef CATTUS_STAMPS
+extern "C" __attribute__((visibility("default"))) int cattus_hip_debug_stamps_w4(unsigned long long* out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_w4), n * sizeof(unsigned long long));
+}
+#endif
+
 hipError_t prepare_wino4() {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_TOTAL);
     const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_TOTAL);
-    return err != hipSuccess ? err : e2;
+    const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_TOTAL);
+    return err != hipSuccess ? err : e2 != hipSuccess ? e2 : e3;
 }
 
 }  // namespace cattus

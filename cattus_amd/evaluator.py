@@ -78,7 +78,8 @@ TOWER_FORMS = {"auto": 0, "direct": 1, "winograd": 2}  # cattus_tower_form
 # harness of the tests and the timing scripts -- forwards the ones it finds there through cattus_hip_create_diag, so that
 # `CATTUS_TOWER64=0 python scripts/...` and monkeypatch.setenv keep working.  CATTUS_WINOGRAD=0/1 (rounds 3-4) maps to tower_form.
 DIAG_SWITCHES = ("CATTUS_CONV_CB", "CATTUS_CONV_PBW", "CATTUS_FUSED_STEM", "CATTUS_T64_CH", "CATTUS_T64_LS", "CATTUS_SPLIT_W", "CATTUS_T64S_HEADS",
-                 "CATTUS_T64S_SHAPE", "CATTUS_TOWER64", "CATTUS_FORCE_GENERIC", "CATTUS_WINO_INPLACE", "CATTUS_ARENA", "CATTUS_WINO_KERNEL")
+                 "CATTUS_T64S_SHAPE", "CATTUS_TOWER64", "CATTUS_FORCE_GENERIC", "CATTUS_WINO_INPLACE", "CATTUS_ARENA", "CATTUS_WINO_KERNEL",
+                 "CATTUS_WINO_PERSIST", "CATTUS_WINO_SPIN")
 
 
 class Stats(C.Structure):

@@ -107,6 +107,8 @@ class SpSummary(C.Structure):
         ("steady_seconds", C.c_double),
         ("steady_node_evals", C.c_uint64),
         ("adjudicated", C.c_uint64),
+        ("steady_plies", C.c_uint64),
+        ("steady_batches", C.c_uint64),
     ]
 
 

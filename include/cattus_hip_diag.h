@@ -23,6 +23,9 @@ extern "C" {
  *   CATTUS_FORCE_GENERIC=1  the one-thread-per-output f32 path (a second checker of the MFMA kernels)
  *   CATTUS_WINO_KERNEL=k16|k4   Winograd form: the 16-frequencies-per-wave kernel (conv3x3_wino_kernel) or the
  *                               4-frequencies x 2x2-blocks one (conv3x3_wino4_kernel); same bits
+ *   CATTUS_WINO_PERSIST=0   the Winograd tower as per-layer launches instead of one launch (tower_wino4_kernel); CATTUS_WINO_SPIN=<n>:
+ *                           polls a hand-off wait of that launch may take before it gives up (a launch that gave up is run again,
+ *                           per layer: the tests set 1 to walk that path)
  *   CATTUS_WINO_INPLACE=0, CATTUS_ARENA=0     memory plan of the Winograd tower (a third activation buffer; separate allocations) */
 int cattus_hip_create_diag(const void* weights, size_t nbytes, const cattus_eval_config* cfg, const char* switches, cattus_eval** out);
 

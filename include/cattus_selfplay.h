@@ -96,6 +96,8 @@ typedef struct cattus_sp_summary {
     double steady_seconds;
     uint64_t steady_node_evals;
     uint64_t adjudicated;       /* games cut at max_game_plies (counted among the draws) */
+    uint64_t steady_plies;      /* moves played in the steady window (positions counts a game's records only when it ends) */
+    uint64_t steady_batches;    /* batches run in the steady window: steady_node_evals / steady_batches = its batch fill */
 } cattus_sp_summary;
 
 typedef struct cattus_sp_result cattus_sp_result;

@@ -26,6 +26,12 @@ EDITS = {
                ("            Mfma<T>::mac(uh0, vh, acc[l][tbv][0]);\n", ""), ("            Mfma<T>::mac(uh1, vh, acc[l][tbv][1]);\n", "")],
     "nodma": [("                issue_chunk(ch_next, freed);\n", "")],
     "noepi": [("    asm volatile(\"s_barrier\" ::: \"memory\");  // every wave has left the chunk buffers", "    if (cin > 0) return;\n    asm volatile(\"s_barrier\" ::: \"memory\");  // every wave has left the chunk buffers")],
+    # the one-launch tower with one of its sc1 / asm pieces replaced by the per-layer kernel's plain form (results may stay right)
+    "p_plainstore": [("        if (PERSIST) asm volatile(\"global_store_dwordx4 %0, %1, off sc1\\n\\ts_nop 1\" ::\"v\"(op), \"v\"(v) : \"memory\");\n        else *reinterpret_cast<f32x4*>(op) = v;",
+                      "        *reinterpret_cast<f32x4*>(op) = v;")],
+    "p_plainskip": [("            if (PERSIST) asm volatile(\"global_load_dwordx4 %0, %1, off sc1\" : \"=&v\"(skip[k]) : \"v\"(sp) : \"memory\");\n            else skip[k] = *reinterpret_cast<const f32x4*>(sp);",
+                     "            skip[k] = *reinterpret_cast<const f32x4*>(sp);")],
+    "p_plainload": [("            if (PERSIST) asm volatile(\"global_load_dwordx4 %0, %1, %2 sc1\"", "            if (false) asm volatile(\"global_load_dwordx4 %0, %1, %2 sc1\"")],
     "plainstore": [("        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (orow + k) * (size_t)cout + cout0 + pc * 4));",
                     "        *reinterpret_cast<f32x4*>(out + (orow + k) * (size_t)cout + cout0 + pc * 4) = v;")],
 }

@@ -699,11 +699,12 @@ def test_device_pointer_entry_points_and_lanes_agree_with_host_entry_point():
 # max_batch >= 192 (or tower_form "winograd").  Two kernels, same bits: k4 = conv3x3_wino4_kernel (kernels_wino4.hip: 4 frequencies x
 # 2x2 blocks per wave, the default wherever it covers the shape), k16 = conv3x3_wino_kernel (kernels_wino.hip: 16 frequencies of one block) ----
 WINO_POLICY_ATOL_VS_F64, WINO_VALUE_ATOL_VS_F64 = 1.5e-6, 5e-7  # measured 5.1e-7 / 1.3e-7 (the direct split tower: 6.3e-7 / 2.1e-7)
-WINO_KERNELS = {"k4": "conv3x3_wino4_kernel", "k16": "conv3x3_wino_kernel"}
+# k4 runs as ONE launch (tower_wino4_kernel: the layers chained by hand-off counters) while its grid fits the device, else per layer
+WINO_KERNELS = {"k4": ("tower_wino4_kernel", "conv3x3_wino4_kernel"), "k16": ("conv3x3_wino_kernel",)}
 
 
 def wino_eval(blob, batch_size, wk, **more):
-    return HipEvaluator(blob, batch_size=batch_size, plane_words=1, dtype="f16x2", switches={"CATTUS_WINO_KERNEL": wk, **more})
+    return HipEvaluator(blob, batch_size=batch_size, plane_words=1, dtype="f16x2", tower_form="winograd", switches={"CATTUS_WINO_KERNEL": wk, **more})
 
 
 @pytest.mark.parametrize("wk", ["k4", "k16"])
@@ -716,7 +717,7 @@ def test_winograd_tower_within_the_reference_tolerance_and_batch_independent(wk)
     planes = z["planes"]
     rep = np.concatenate([planes] * 50)[:197]
     with wino_eval(blob, 256, wk) as ev:
-        assert ev.tower_kernel() == WINO_KERNELS[wk]
+        assert ev.tower_kernel() in WINO_KERNELS[wk]
         p, v = ev.eval(planes)
         pr, vr = ev.eval(rep)
         assert ev.stats()["saturated"] == 0
@@ -727,9 +728,9 @@ def test_winograd_tower_within_the_reference_tolerance_and_batch_independent(wk)
     with HipEvaluator(blob, batch_size=128, plane_words=1, dtype="f16x2", switches={}) as ev:
         assert ev.tower_kernel() == "conv3x3_splitw_kernel"  # small batches: the direct kernels' small tiles
     with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2", switches={}) as ev:
-        assert ev.tower_kernel() == "conv3x3_wino4_kernel"  # what cattus_hip_create chooses by itself
+        assert ev.tower_kernel() == "tower_wino4_kernel"  # what cattus_hip_create chooses by itself
     with HipEvaluator(blob, batch_size=16, plane_words=1, dtype="f16x2", tower_form="winograd", switches={"CATTUS_WINO_KERNEL": wk}) as ev:
-        assert ev.tower_kernel() == WINO_KERNELS[wk]  # the form is a field of the configuration: a 16-leaf evaluator in Winograd form ...
+        assert ev.tower_kernel() in WINO_KERNELS[wk]  # the form is a field of the configuration: a 16-leaf evaluator in Winograd form ...
         ps, vs = ev.eval(planes)
     assert (ps == p).all() and (vs == v).all()  # ... gives a leaf the bits the 256-leaf evaluator gives it
     with HipEvaluator(blob, batch_size=256, plane_words=1, dtype="f16x2", tower_form="direct", switches={}) as ev:
@@ -756,7 +757,7 @@ def test_winograd_kernels_agree_bit_for_bit(shape):
     d = NetDesc(**CHESS, blocks=blocks, filters=filters, vhc=8, phc=8)
     blob = seeded_blob(d, 21)
     planes = synth.random_chess_planes(n, 13)
-    with wino_eval(blob, max(n, 192), "k4") as ev:
+    with wino_eval(blob, max(n, 192), "k4", CATTUS_WINO_PERSIST="0") as ev:
         assert ev.tower_kernel() == "conv3x3_wino4_kernel"
         a = ev.eval(planes)
         a2 = ev.eval(planes[: n // 3 + 1])
@@ -773,6 +774,49 @@ def test_winograd_kernels_agree_bit_for_bit(shape):
         assert np.abs(a[0] - b[0]).max() < 2e-6 and np.abs(a[1] - b[1]).max() < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(3, 128, 256), (3, 128, 512), (20, 256, 256), (2, 384, 168), (2, 192, 77)])
+def test_one_launch_winograd_tower_equals_the_per_layer_launches(shape):
+    """tower_wino4_kernel -- every layer behind the stem in one launch, a workgroup keeping its (4 boards x 64 couts) tile through all
+    of them, the layers chained by a counter per (layer, board group) -- against the same layers as launches of their own
+    (CATTUS_WINO_PERSIST=0): the same bits, on a full grid (one workgroup per CU), on partial batches of the same evaluator, on both
+    lanes back to back, and again after many passes (stale lines in a CU's L1 or a missed hand-off would show as wrong rows)."""
+    blocks, filters, n = shape
+    d = NetDesc(**CHESS, blocks=blocks, filters=filters, vhc=8, phc=8)
+    blob = seeded_blob(d, 31)
+    planes = synth.random_chess_planes(n, 17)
+    with wino_eval(blob, n, "k4", CATTUS_WINO_PERSIST="0") as ev:
+        assert ev.tower_kernel() == "conv3x3_wino4_kernel"
+        want = ev.eval(planes)
+    with wino_eval(blob, n, "k4") as ev:
+        assert ev.tower_kernel() == "tower_wino4_kernel"  # (n / 4 board groups) x (filters / 64 cout groups) <= 256 CUs
+        for rep in range(6):
+            got = ev.eval(planes)  # alternates between the lanes' buffers
+            assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), rep
+            k = 1 + (rep * 37) % n
+            part = ev.eval(planes[:k])
+            assert (part[0] == want[0][:k]).all() and (part[1] == want[1][:k]).all(), (rep, k)
+        assert ev.stats()["saturated"] == 0
+        assert ev.tower_kernel() == "tower_wino4_kernel"  # no hand-off wait gave up
+
+
+def test_one_launch_tower_whose_hand_off_gives_up_is_run_again_per_layer():
+    """The failure path of the one-launch tower: with a budget of ONE poll per hand-off wait (CATTUS_WINO_SPIN=1) some workgroup finds
+    its producers not yet counted in, raises the launch's error word and goes on on rows that are not ready; the host finds the word
+    behind the batch, throws the outputs away, runs the batch on the per-layer launches and stays there.  The caller sees the right
+    bits and an evaluator that says which kernel it now runs."""
+    d = NetDesc(**CHESS, blocks=6, filters=256, vhc=8, phc=8)
+    blob = seeded_blob(d, 33)
+    planes = synth.random_chess_planes(256, 19)
+    with wino_eval(blob, 256, "k4", CATTUS_WINO_PERSIST="0") as ev:
+        want = ev.eval(planes)
+    with wino_eval(blob, 256, "k4", CATTUS_WINO_SPIN="1") as ev:
+        assert ev.tower_kernel() == "tower_wino4_kernel"
+        for _ in range(3):
+            got = ev.eval(planes)
+            assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+        assert ev.tower_kernel() == "conv3x3_wino4_kernel"  # a wait gave up somewhere in 12 layers x 256 workgroups x 3 passes
+
+
 @pytest.mark.parametrize("wk", ["k4", "k16"])
 def test_winograd_tower_on_the_reference_made_fixture_with_the_reference_positions(wk):
     """tests/golden/chess_4x128.npz: a Winograd-shaped network (8x8 board, 128 filters) evaluated by the reference's own module
@@ -783,7 +827,7 @@ def test_winograd_tower_on_the_reference_made_fixture_with_the_reference_positio
     planes = z["planes"]
     assert len(planes) == 64
     with wino_eval(blob, 256, wk) as ev:
-        assert ev.tower_kernel() == WINO_KERNELS[wk]
+        assert ev.tower_kernel() in WINO_KERNELS[wk]
         p, v = ev.eval(planes)
         assert ev.stats()["saturated"] == 0
     assert outputs_equal_ref_tol(p, v, z["policy"], z["value"])
@@ -802,7 +846,7 @@ def test_winograd_tower_memory_plans_agree_bit_for_bit(wk):
     got = {}
     for arena, inplace in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
         with wino_eval(blob, 256, wk, CATTUS_ARENA=arena, CATTUS_WINO_INPLACE=inplace) as ev:
-            assert ev.tower_kernel() == WINO_KERNELS[wk]
+            assert ev.tower_kernel() in WINO_KERNELS[wk]
             a = ev.eval(planes)
             b = ev.eval(planes[:77])  # the second call takes the other lane's buffers when the first one's are still warm
             c = ev.eval(planes)
@@ -825,7 +869,7 @@ def test_winograd_tower_tracks_the_f32_tower_at_full_size(net, n, bound):
     with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f32") as ev:
         want_p, want_v = ev.eval(planes)
     with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f16x2", switches={}) as ev:
-        assert ev.tower_kernel() == "conv3x3_wino4_kernel"  # the kernel bench.py's headline is timed on
+        assert ev.tower_kernel() == ("tower_wino4_kernel" if net == "20x256" else "conv3x3_wino4_kernel")  # what bench.py's headline is timed on
         got_p, got_v = ev.eval(planes)
     assert np.isfinite(got_p).all() and np.isfinite(got_v).all()
     assert np.abs(got_p - want_p).max() <= bound[0] and np.abs(got_v - want_v).max() <= bound[1]
@@ -845,7 +889,7 @@ def test_winograd_tower_counts_inputs_that_leave_the_f16_range(wk):
         t["_conv1._bn.weight"] = t["_conv1._bn.weight"] * np.float32(scale)
         blob = pack_tensors(d, t)
         with wino_eval(blob, 256, wk) as ev:
-            assert ev.tower_kernel() == WINO_KERNELS[wk]
+            assert ev.tower_kernel() in WINO_KERNELS[wk]
             p, v = ev.eval(planes)
             assert (ev.stats()["saturated"] > 0) == saturates
         assert np.isfinite(p).all() and np.isfinite(v).all()
