@@ -51,7 +51,7 @@ using w4_int = std::integral_constant<int, V>;
 
 // ---- diagnostic build only (-DCATTUS_STAMPS, python -m cattus_amd.build --diag; scripts/stamps_w4.py): per-wave cycle stamps ----
 #ifdef CATTUS_STAMPS
-__device__ unsigned long long g_stamps_w4[1024 * 4 * 8];
+__device__ unsigned long long g_stamps_w4[1024 * 4 * 10];
 #define W4_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
 #define W4_STAMP_RT(i) st_[i] = __builtin_amdgcn_s_memrealtime()
 #else
@@ -82,7 +82,7 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     constexpr bool has_res = RES == 1;
 
 #ifdef CATTUS_STAMPS
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 8: behind the hand-off wait, 9: behind the last store's drain
 #endif
     W4_STAMP(0);
     W4_STAMP_RT(6);
@@ -181,6 +181,7 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
         }
         asm volatile("s_barrier" ::: "memory");
     }
+    W4_STAMP(8);
     load_chunk(first, 0);
     load_chunk(pend, 1);  // cin >= 128: at least four chunks
     load_ustage(ring[2], wks, 2);
@@ -480,7 +481,9 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     if (PERSIST) {
         // every storing wave drains its stores, the workgroup meets, ONE lane counts the workgroup in (agent scope): the order the
         // guide's hand-off table was measured in.  The barrier also keeps the next layer's LDS writes behind this layer's last LDS reads
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4_STAMP(9);
+        asm volatile("s_barrier" ::: "memory");
         if (tid == 0) __hip_atomic_fetch_add(sync.done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef CATTUS_STAMPS
@@ -488,7 +491,7 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     W4_STAMP_RT(7);
     if (lane == 0 && blockIdx.x < 1024) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) g_stamps_w4[((size_t)blockIdx.x * 4 + q) * 8 + i] = st_[i];
+        for (int i = 0; i < 10; i++) g_stamps_w4[((size_t)blockIdx.x * 4 + q) * 10 + i] = st_[i];
     }
 #endif
 }

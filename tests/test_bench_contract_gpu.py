@@ -27,8 +27,9 @@ def test_bench_prints_one_json_line_on_stdout():
     assert out["n_gpus"] == 1 and out["steps"] == 6 and out["dtype"] == "f16x2" and out["vs_baseline"] is None
     assert "workload" in out["config"] and "model" not in out["config"]
     r = out["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["kernel"] == "conv3x3_wino_kernel"  # batch 256 on 8x8 boards: the split tower in Winograd form
+    assert r["bound"] in ("mfma", "l2_delivery") and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"] == "tower_wino4_kernel"  # batch 256 on 8x8 boards: the split tower in Winograd form, every layer in one launch
+    assert r["delivery"]["workgroups"] == 256 and 0 < r["delivery"]["frac_of_roof"][0] < 1.5
     c = out["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert abs(out["value"] - 256 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
