@@ -297,14 +297,14 @@ def pack_roofline(torch, ev_lib, dev, stream, leaves: int = 262144, reps: int = 
     }
 
 
-TRAFFIC_FILE = "profiles/r04_pmc_hbm_traffic.json"
+TRAFFIC_FILE = "profiles/r05_pmc_hbm_traffic.json"
 
 
 def kernels_sha256() -> str:
     """Identity of the kernel CODE the traffic counters were collected on: sha256 of the kernel sources (device_common.h,
-    kernels.h, kernels.hip, kernels_t64s.hip, kernels_wino.hip) with their `//` comments and all white space removed (an edited
+    kernels.h, kernels.hip, kernels_t64s.hip, kernels_wino.hip, kernels_wino4.hip) with their `//` comments and all white space removed (an edited
     comment does not make a measurement stale; the files have no block comments and no `//` inside a string literal)."""
-    names = ("device_common.h", "kernels.h", "kernels.hip", "kernels_t64s.hip", "kernels_wino.hip")
+    names = ("device_common.h", "kernels.h", "kernels.hip", "kernels_t64s.hip", "kernels_wino.hip", "kernels_wino4.hip")
     text = "".join((ROOT / "cattus_amd" / "csrc" / name).read_text() for name in names)
     code = "".join("".join(line.split("//", 1)[0].split()) for line in text.splitlines())
     return hashlib.sha256(code.encode()).hexdigest()
@@ -745,7 +745,9 @@ def main():
             "avg_launch_us": r["launch_us"],
             "avg_launch_note": "per-launch start / stop HIP events (hipExtLaunchKernelGGL) on the launches of the same forward, in a pass of "
                                "its own right behind the timed steps: the stamps cost ~0.5 us per launch, so launches_per_step x avg_launch_us "
-                               "can exceed ms_per_step by 1-2 % -- `achieved` and `frac` are low by that much, never high",
+                               "can exceed ms_per_step by 1-2 % -- `achieved` and `frac` are low by that much, never high.  tower_wino4_kernel runs every "
+                               "layer behind the stem in ONE launch: its duration (+ the stem's) is divided by the 1 + 2 x blocks layers, i.e. "
+                               "avg_launch_us is per LAYER and launches_per_step counts layers",
             "launches_per_step": r["launches"],
             "flop_per_launch": flop_per_launch,
             "mfma_terms_per_multiply_add": mfma_terms(dtype, r["kernel"]),

@@ -10,8 +10,13 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 QUIET="--lanes 1 --settle-seconds 0 --no-cpu-baseline --selfplay-seconds 0 --agreement-plies 0 --no-f32 --no-bf16 --no-f16 --no-smi"
+# PARTS (default "bench dtypes workloads") selects what runs: one gpurun call holds 20 minutes, the whole collection takes more
+PARTS=${PARTS:-bench dtypes workloads}
+if [[ " $PARTS " == *" bench "* ]]; then
 echo "== bench (defaults)"; timeout -k 10 900 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 tail -c 400 "$OUT/bench.json"; echo
+fi
+if [[ " $PARTS " == *" dtypes "* ]]; then
 for dt in ${DTYPES:-f16x2 bf16 f16 f32}; do
   echo "== rocprofv3 kernel stats, $dt"
   STEPS=50; [ $dt = f32 ] && STEPS=10
@@ -27,14 +32,17 @@ for dt in ${DTYPES:-f16x2 bf16 f16 f32}; do
   rm -rf "$OUT/$dt"
 done
 python3 scripts/make_traffic_json.py "$OUT" > "$OUT/pmc_hbm_traffic.json"
+fi
 # BASELINE configs 2 and 5 as the driver would run them (evaluator-only line + kernel stats), every tower
+if [[ " $PARTS " == *" workloads "* ]]; then
 for wl in hex7_6x64 chess40x384; do
   echo "== bench --workload $wl"
   timeout -k 10 600 python3 bench.py --workload $wl --steps 100 --warmup 10 --no-cpu-baseline --no-f32 > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err" || exit 1
   for dt in f16x2 bf16; do
-    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_${wl}_$dt" -o bench -- python3 bench.py --workload $wl --dtype $dt --steps 50 --warmup 5 $QUIET > /dev/null 2> "$OUT/stats_${wl}_$dt.err" || exit 1
+    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_${wl}_$dt" -o bench -- python3 bench.py --workload $wl --dtype $dt --steps 50 --warmup 5 $QUIET > "$OUT/stats_bench_${wl}_$dt.json" 2> "$OUT/stats_${wl}_$dt.err" || exit 1
     find "$OUT/stats_${wl}_$dt" -name '*kernel_stats.csv' -exec cp {} "$OUT/bench_${wl}_${dt}_kernel_stats.csv" \;
     rm -rf "$OUT/stats_${wl}_$dt"
   done
 done
+fi
 du -sh "$OUT"

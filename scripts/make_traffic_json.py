@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/rNN_pmc_hbm_traffic.json from the per-dtype PMC summaries of scripts/collect_profiles.sh:
-    python scripts/make_traffic_json.py gpurun_out/TAG > profiles/r04_pmc_hbm_traffic.json
+    python scripts/make_traffic_json.py gpurun_out/TAG > profiles/r05_pmc_hbm_traffic.json
 The file carries the sha256 of the code of cattus_amd/csrc/kernels.hip (comments and white space removed) the passes ran on; bench.py withholds the traffic figure
 when the kernels have changed since (it cannot collect PMC counters inside its own process)."""
 import hashlib
@@ -41,9 +41,11 @@ def base_name(k: str) -> str:
     return k.replace("void ", "").replace("cattus::", "").split("<")[0].split("(")[0].strip()
 
 
-TOWER = {"f16x2": "conv3x3_wino_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
+LAYERS_PER_LAUNCH = {"tower_wino4_kernel": 40}  # chess 20x256: 2 x 20 layers behind the stem
+TOWER = {"f16x2": "tower_wino4_kernel", "bf16": "conv3x3_mfma_v2_kernel", "f16": "conv3x3_mfma_v2_kernel", "f32": "conv3x3_mfma_v2_kernel"}
 # the f16x2 tower at batch 256 runs its 40 layers behind the stem in Winograd form: f32 rows in and out (+ the skip rows in 20 of them),
-# the layer's transformed weights U (16 frequencies x 256 x 256 pairs = 4.19 MB) once
+# the layer's transformed weights U (16 frequencies x 256 x 256 pairs = 4.19 MB) once.  tower_wino4_kernel runs all 40 in ONE launch:
+# its counters are divided by LAYERS_PER_LAUNCH so that the figure is per layer, like bench.py's roofline.achieved
 ALG["f16x2"] = (20 * (2 * ACT * 4 + 16 * 256 * 256 * 4) + 20 * (3 * ACT * 4 + 16 * 256 * 256 * 4)) / 40
 for dtype in ("f16x2", "bf16", "f16", "f32"):
     f = tag / f"pmc_summary_{dtype}.json"
@@ -61,7 +63,11 @@ for dtype in ("f16x2", "bf16", "f16", "f32"):
         a[2][k[:110]] = {"traffic_bytes_per_launch": v["traffic_bytes_per_launch"], "launches": n}
     entry = {}
     for name, (tot, n, variants) in acc.items():
-        entry[name] = {"traffic_bytes_per_launch": int(tot / n), "launches": n}
+        per = LAYERS_PER_LAUNCH.get(name, 1)
+        entry[name] = {"traffic_bytes_per_launch": int(tot / n / per), "launches": n}
+        if per > 1:
+            entry[name]["layers_per_launch"] = per
+            entry[name]["traffic_bytes_per_whole_launch"] = int(tot / n)
         if len(variants) > 1:
             entry[name]["by_variant"] = variants
         if name == TOWER[dtype]:
