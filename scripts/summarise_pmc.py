@@ -17,7 +17,7 @@ for path in glob.glob(f"{out_dir}/pmc_*/**/*counter_collection.csv", recursive=T
             a[1] += 1
 res = {}
 for k, counters in sorted(acc.items()):
-    if not any(s in k for s in ("conv3x3", "planes_to_tensor", "head_gemm", "head_conv", "pack_planes", "tower64", "head_fc")):
+    if not any(s in k for s in ("conv3x3", "planes_to_tensor", "head_gemm", "head_conv", "pack_planes", "tower64", "tower_wino4", "head_fc")):
         continue
     e = {c: {"avg_per_launch": v[0] / v[1], "launches": v[1]} for c, v in counters.items()}
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
