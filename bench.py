@@ -55,13 +55,13 @@ def mfma_terms(dtype: str, kernel: str) -> float:
     return MFMA_TERMS[dtype] * (16.0 / 36.0 if kernel in WINOGRAD_KERNELS else 1.0)
 
 
-WINOGRAD_KERNELS = ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "tower_wino4_kernel")
+WINOGRAD_KERNELS = ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "tower_wino4_kernel", "conv3x3_wino8_kernel")
 # What the chip's L2s deliver to the CUs when every CU streams rows that its XCD's L2 holds (MI355X_MICROARCH.md, "Indexed rows:
 # gather into LDS": 66-73 GB/s per CU, 16.8-18.8 TB/s chip-wide): the roof of a kernel whose loop is a stream of L2-resident operands
 L2_DELIVERY_TBPS = (16.8, 18.8)
 # (rows, couts) of a workgroup's tile: the bytes a workgroup pulls from L2 per layer are its U block (cout_wg x cin x 16 frequencies x
 # (hi, lo) f16 = 64 B per (cout, cin)) + its input rows (rows_wg x cin x 4 B) + its skip tile (rows_wg x cout_wg x 4 B, every second layer)
-WINOGRAD_WG_TILE = {"conv3x3_wino_kernel": (128, 128), "conv3x3_wino4_kernel": (256, 64), "tower_wino4_kernel": (256, 64)}
+WINOGRAD_WG_TILE = {"conv3x3_wino_kernel": (128, 128), "conv3x3_wino4_kernel": (256, 64), "tower_wino4_kernel": (256, 64), "conv3x3_wino8_kernel": (256, 64)}
 
 
 def delivery_roof(kernel: str, filters: int, rows: int, launch_us: float):
@@ -302,9 +302,9 @@ TRAFFIC_FILE = "profiles/r05_pmc_hbm_traffic.json"
 
 def kernels_sha256() -> str:
     """Identity of the kernel CODE the traffic counters were collected on: sha256 of the kernel sources (device_common.h,
-    kernels.h, kernels.hip, kernels_t64s.hip, kernels_wino.hip, kernels_wino4.hip) with their `//` comments and all white space removed (an edited
+    kernels.h, kernels.hip, kernels_t64s.hip, kernels_wino.hip, kernels_wino4.hip, kernels_wino8.hip) with their `//` comments and all white space removed (an edited
     comment does not make a measurement stale; the files have no block comments and no `//` inside a string literal)."""
-    names = ("device_common.h", "kernels.h", "kernels.hip", "kernels_t64s.hip", "kernels_wino.hip", "kernels_wino4.hip")
+    names = ("device_common.h", "kernels.h", "kernels.hip", "kernels_t64s.hip", "kernels_wino.hip", "kernels_wino4.hip", "kernels_wino8.hip")
     text = "".join((ROOT / "cattus_amd" / "csrc" / name).read_text() for name in names)
     code = "".join("".join(line.split("//", 1)[0].split()) for line in text.splitlines())
     return hashlib.sha256(code.encode()).hexdigest()

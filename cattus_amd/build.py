@@ -12,7 +12,7 @@ CSRC = PKG / "csrc"
 ROOT = PKG.parent
 
 HIP_LIB = PKG / "libcattus_hip.so"
-HIP_SOURCES = [CSRC / "kernels.hip", CSRC / "kernels_t64s.hip", CSRC / "kernels_wino.hip", CSRC / "kernels_wino4.hip", CSRC / "evaluator.hip"]
+HIP_SOURCES = [CSRC / "kernels.hip", CSRC / "kernels_t64s.hip", CSRC / "kernels_wino.hip", CSRC / "kernels_wino4.hip", CSRC / "kernels_wino8.hip", CSRC / "evaluator.hip"]
 HIP_DEPS = HIP_SOURCES + [CSRC / "kernels.h", CSRC / "device_common.h", ROOT / "include" / "cattus_hip.h"]
 
 # -ffp-contract=off: the f32 path promises a fixed fmaf-chain order, so the compiler

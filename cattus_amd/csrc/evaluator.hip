@@ -291,6 +291,7 @@ struct cattus_eval {
     // which Winograd kernel: the 4-frequencies x 2x2-blocks one (kernels_wino4.hip) wherever it covers the shape, else the
     // 16-frequencies one (kernels_wino.hip); same bits; diagnostic switch CATTUS_WINO_KERNEL=k16|k4
     bool wino_k4 = true;
+    bool wino_k8 = false;  // CATTUS_WINO_KERNEL=k8: the eight-wave kernel (kernels_wino8.hip), per layer
     // The Winograd tower as ONE launch (tower_wino4_kernel) while its grid fits the device, one workgroup per CU (diagnostic switch
     // CATTUS_WINO_PERSIST=0: per-layer launches; CATTUS_WINO_SPIN=<polls>: the budget of a hand-off wait).  persist_ok falls when
     // a launch reported a wait that gave up: the batch is run again on the per-layer launches, and so is every later one.
@@ -802,11 +803,12 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
             const bool wino = d.blocks > 0 && e->c1[0]->wu.p != nullptr;
             auto conv = [&](const ConvLayer& c, const void* in, const void* res, void* out, int lflags) {
                 hipEvent_t s0 = ev(false), s1 = ev(true);
-                if (wino && e->wino_k4) launch_conv3x3_wino4((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
+                if (wino && e->wino_k8) launch_conv3x3_wino8((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
+                else if (wino && e->wino_k4) launch_conv3x3_wino4((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
                 else if (wino) launch_conv3x3_wino((const float*)in, c.wu.p, c.bw.as<float>(), (const float*)res, (float*)out, nb, FP, FP, st, s0, s1, e->conv_opts.saturated);
                 else launch_conv3x3_mfma(e->act, in, wptr(c), c.b.as<float>(), res, out, nb, FP, FP, S, st, s0, s1, nullptr, wflag | lflags, e->conv_opts);
             };
-            if (wino && L.tower_nlayers && e->persist_ok.load(std::memory_order_relaxed) && wino4_tower_fits(nb, FP, e->cus)) {
+            if (wino && !e->wino_k8 && L.tower_nlayers && e->persist_ok.load(std::memory_order_relaxed) && wino4_tower_fits(nb, FP, e->cus)) {
                 // every layer behind the stem in ONE launch: counters and error word zeroed ahead of it on the same stream, the error word
                 // copied to page-locked memory behind it (eval_host reads it when the batch is back; the device entry points at their next call)
                 hipEvent_t s0 = ev(false), s1 = ev(true);
@@ -1048,7 +1050,7 @@ CATTUS_API const char* cattus_hip_tower_kernel(const cattus_eval* e) {
     if (!e->tuned) return "conv3x3_generic_kernel";
     if (e->tower64) return "tower64_lds_kernel";
     if (e->tower64s) return "tower64_split_kernel";
-    if (e->act == Act::F16S) return e->d.blocks > 0 && e->c1[0]->wu.p ? (e->wino_k4 ? (e->lanes[0].tower_nlayers && e->persist_ok.load() && wino4_tower_fits(e->bpad, e->fpad, e->cus) ? "tower_wino4_kernel" : "conv3x3_wino4_kernel") : "conv3x3_wino_kernel") : e->split_wfrag ? "conv3x3_splitw_kernel" : "conv3x3_split_kernel";
+    if (e->act == Act::F16S) return e->d.blocks > 0 && e->c1[0]->wu.p ? (e->wino_k8 ? "conv3x3_wino8_kernel" : e->wino_k4 ? (e->lanes[0].tower_nlayers && e->persist_ok.load() && wino4_tower_fits(e->bpad, e->fpad, e->cus) ? "tower_wino4_kernel" : "conv3x3_wino4_kernel") : "conv3x3_wino_kernel") : e->split_wfrag ? "conv3x3_splitw_kernel" : "conv3x3_split_kernel";
     return "conv3x3_mfma_v2_kernel";
 }
 
@@ -1212,8 +1214,9 @@ int create_impl(const void* weights, size_t nbytes, const cattus_eval_config* cf
     {
         // the 4-frequency kernel wherever it covers the layer shape (filters a multiple of 64), else the 16-frequency one (128)
         const char* wk = sw.get("CATTUS_WINO_KERNEL");
-        if (wk && strcmp(wk, "k16") != 0 && strcmp(wk, "k4") != 0) return fail(CATTUS_E_INVALID, "CATTUS_WINO_KERNEL is k16 or k4");
-        e->wino_k4 = wk ? strcmp(wk, "k4") == 0 : wino4_supported(e->bpad, e->fpad, e->fpad, d.board);
+        if (wk && strcmp(wk, "k16") != 0 && strcmp(wk, "k4") != 0 && strcmp(wk, "k8") != 0) return fail(CATTUS_E_INVALID, "CATTUS_WINO_KERNEL is k16, k4 or k8");
+        e->wino_k8 = wk && strcmp(wk, "k8") == 0;
+        e->wino_k4 = wk ? strcmp(wk, "k4") == 0 || e->wino_k8 : wino4_supported(e->bpad, e->fpad, e->fpad, d.board);
     }
     {
         const char* wp = sw.get("CATTUS_WINO_PERSIST");

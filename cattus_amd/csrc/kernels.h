@@ -105,6 +105,11 @@ bool wino4_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S);
 void launch_conv3x3_wino4(const float* in, const void* wu, const float* bias, const float* res, float* out, uint32_t bpad, uint32_t cin,
                           uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat);
 hipError_t prepare_wino4();
+// ---- K1w8: the same layer on EIGHT waves of 128 accumulator registers, two per SIMD (kernels_wino8.hip); same arguments, U and bits ----
+bool wino8_supported(uint32_t bpad, uint32_t cin, uint32_t cout, uint32_t S);
+void launch_conv3x3_wino8(const float* in, const void* wu, const float* bias, const float* res, float* out, uint32_t bpad, uint32_t cin,
+                          uint32_t cout, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned* sat);
+hipError_t prepare_wino8();
 // The whole Winograd tower in one launch (tower_wino4_kernel): a table of its layers in device memory (an even number: residual blocks,
 // the first layer of a block without skip rows, the second with; res may equal out), `ready` = nlayers x (bpad / 4) zeroed counters, `err` a zeroed word the launch sets when a hand-off wait ran out of
 // `spin_budget` polls (the outputs are then invalid: run the batch on the per-layer launches).  Only while wino4_tower_fits: every

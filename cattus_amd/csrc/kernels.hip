@@ -2075,6 +2075,8 @@ hipError_t prepare_device() {
     if (err == hipSuccess) err = e4;
     const hipError_t e5 = prepare_wino4();
     if (err == hipSuccess) err = e5;
+    const hipError_t e6 = prepare_wino8();
+    if (err == hipSuccess) err = e6;
     return err;
 }
 

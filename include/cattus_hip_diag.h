@@ -21,8 +21,8 @@ extern "C" {
  *   CATTUS_CONV_CB=1|2, CATTUS_CONV_PBW=1|2   tile shapes of the per-layer conv kernels
  *   CATTUS_FUSED_STEM=0     plane pack as its own launch in front of the stem
  *   CATTUS_FORCE_GENERIC=1  the one-thread-per-output f32 path (a second checker of the MFMA kernels)
- *   CATTUS_WINO_KERNEL=k16|k4   Winograd form: the 16-frequencies-per-wave kernel (conv3x3_wino_kernel) or the
- *                               4-frequencies x 2x2-blocks one (conv3x3_wino4_kernel); same bits
+ *   CATTUS_WINO_KERNEL=k16|k4|k8   Winograd form: the 16-frequencies-per-wave kernel (conv3x3_wino_kernel), the 4-frequencies x
+ *                               2x2-blocks one (conv3x3_wino4_kernel / tower_wino4_kernel) or the eight-wave one (conv3x3_wino8_kernel); same bits
  *   CATTUS_WINO_PERSIST=0   the Winograd tower as per-layer launches instead of one launch (tower_wino4_kernel); CATTUS_WINO_SPIN=<n>:
  *                           polls a hand-off wait of that launch may take before it gives up (a launch that gave up is run again,
  *                           per layer: the tests set 1 to walk that path)

@@ -9,7 +9,7 @@ mkdir -p /tmp/variants
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16 -Iinclude \
   $flags -c cattus_amd/csrc/$tu.hip -o /tmp/variants/${tu}_$name.o
 objs=""
-for s in kernels kernels_t64s kernels_wino kernels_wino4 evaluator; do
+for s in kernels kernels_t64s kernels_wino kernels_wino4 kernels_wino8 evaluator; do
   if [ $s = $tu ]; then objs="$objs /tmp/variants/${tu}_$name.o"; else objs="$objs cattus_amd/build/hip/$s.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -fvisibility=hidden -o cattus_amd/libcattus_hip_$name.so $objs -lpthread -ldl

@@ -700,7 +700,7 @@ def test_device_pointer_entry_points_and_lanes_agree_with_host_entry_point():
 # 2x2 blocks per wave, the default wherever it covers the shape), k16 = conv3x3_wino_kernel (kernels_wino.hip: 16 frequencies of one block) ----
 WINO_POLICY_ATOL_VS_F64, WINO_VALUE_ATOL_VS_F64 = 1.5e-6, 5e-7  # measured 5.1e-7 / 1.3e-7 (the direct split tower: 6.3e-7 / 2.1e-7)
 # k4 runs as ONE launch (tower_wino4_kernel: the layers chained by hand-off counters) while its grid fits the device, else per layer
-WINO_KERNELS = {"k4": ("tower_wino4_kernel", "conv3x3_wino4_kernel"), "k16": ("conv3x3_wino_kernel",)}
+WINO_KERNELS = {"k4": ("tower_wino4_kernel", "conv3x3_wino4_kernel"), "k16": ("conv3x3_wino_kernel",), "k8": ("conv3x3_wino8_kernel",)}
 
 
 def wino_eval(blob, batch_size, wk, **more):
@@ -750,7 +750,7 @@ def test_winograd_tower_form_is_refused_where_no_kernel_covers_the_shape():
 
 @pytest.mark.parametrize("shape", [(3, 128, 256), (2, 192, 200), (2, 256, 24), (1, 384, 512)])
 def test_winograd_kernels_agree_bit_for_bit(shape):
-    """conv3x3_wino4_kernel against conv3x3_wino_kernel: per accumulator the same MFMA sequence, V and Y combined in the same order --
+    """conv3x3_wino4_kernel and conv3x3_wino8_kernel against conv3x3_wino_kernel: per accumulator the same MFMA sequence, V and Y combined in the same order --
     the same bits, on full, ragged and multi-round grids (192 filters: the 4-frequency kernel alone covers them, checked against the
     direct form's tolerance instead)."""
     blocks, filters, n = shape
@@ -763,6 +763,11 @@ def test_winograd_kernels_agree_bit_for_bit(shape):
         a2 = ev.eval(planes[: n // 3 + 1])
         assert ev.stats()["saturated"] == 0
     assert (a2[0] == a[0][: n // 3 + 1]).all() and (a2[1] == a[1][: n // 3 + 1]).all()
+    with wino_eval(blob, max(n, 192), "k8") as ev:  # the eight-wave kernel (two waves per SIMD; built, measured, not the default)
+        assert ev.tower_kernel() == "conv3x3_wino8_kernel"
+        c8 = ev.eval(planes)
+        assert ev.stats()["saturated"] == 0
+    assert (a[0] == c8[0]).all() and (a[1] == c8[1]).all()
     if filters % 128 == 0:
         with wino_eval(blob, max(n, 192), "k16") as ev:
             assert ev.tower_kernel() == "conv3x3_wino_kernel"

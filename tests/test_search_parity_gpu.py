@@ -40,7 +40,7 @@ BF16_VISIT_L1_MAX = 0.09
 # at most 2 chosen moves may differ (>= 99.2 %), see profiles/r03_search_agreement.json for 2,048 and 3,888 searches
 F16X2_MOVE_AGREEMENT_MIN = 0.992
 F16X2_VISIT_L1_MEAN_MAX = 4e-4
-WINOGRAD_KERNELS = ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "tower_wino4_kernel")  # the Winograd form's kernels (same bits)
+WINOGRAD_KERNELS = ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "tower_wino4_kernel", "conv3x3_wino8_kernel")  # the Winograd form's kernels (same bits)
 
 
 def _positions_of(lines, upto):
