@@ -106,19 +106,21 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     // ---- the U ring: slot l = the U stage (k-step, frequency 4 q + l) = [cb0 hi, cb0 lo, cb1 hi, cb1 lo] ----
     const char* wb0 = reinterpret_cast<const char*>(wu) + ((size_t)(cout0 >> 5) * nks * 16 + 4 * q) * SW_STAGE;
     const size_t wcb = (size_t)nks * 16 * SW_STAGE;  // from cout block 0 to cout block 1
-    const uint32_t voff0 = lane * 16;
+    const uint32_t voff0 = lane * 16, voff1 = lane * 16 + 4096;
     u32x4 ring[4][4];
-    // the four U stages of a k-step are 2 KiB apart: l = 0, 1 as immediate offsets from the k-step's base, l = 2, 3 from base + 4 KiB
-    // (two scalar additions per k-step and cout block instead of two per load)
+    // the four U stages of a k-step are 2 KiB apart: l = 0, 1 as immediate offsets from the k-step's base, l = 2, 3 through a second
+    // lane offset 4 KiB further (one base pointer per k-step and cout block: every scalar addition in this loop costs the wave an
+    // issue slot that nothing hides)
 #define W4_ULOAD(OFF)                                                                                                                      \
     asm volatile("global_load_dwordx4 %0, %4, %5 offset:" #OFF "\n\tglobal_load_dwordx4 %1, %4, %5 offset:" #OFF "+1024\n\t"             \
                  "global_load_dwordx4 %2, %4, %6 offset:" #OFF "\n\tglobal_load_dwordx4 %3, %4, %6 offset:" #OFF "+1024"                  \
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)                                                                                  \
-                 : "v"(voff0), "s"(p0), "s"(p1)                                                                                            \
+                 : "v"(voff), "s"(p0), "s"(p1)                                                                                             \
                  : "memory")
     auto load_ustage = [&](u32x4(&slot)[4], const char* pk, int l) __attribute__((always_inline)) {  // pk: the k-step's U (this wave's frequency row)
-        const char* p0 = pk + (l >> 1) * 4096;
-        const char* p1 = p0 + wcb;
+        const char* p0 = pk;
+        const char* p1 = pk + wcb;
+        const uint32_t voff = l >> 1 ? voff1 : voff0;
         u32x4 a, b, c, d;
         if (l & 1) W4_ULOAD(2048);
         else W4_ULOAD(0);
@@ -233,16 +235,21 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
             dst[2 * g] = __builtin_bit_cast(uint32_t, h0);
             dst[2 * g + 1] = __builtin_bit_cast(uint32_t, h1);
         } else {
-            // lo = f16(x - hi), exact in f32: one mixed-precision fma per element (v_fma_mixlo/hi_f16), in asm -- the compiler rewrites the
-            // C form into convert - subtract - convert; the s_nop covers the partial-register write (kernels_wino.hip)
+            // lo = f16(x - hi): the difference is exact in f32 (v_fma_mix_f32 takes hi as the f16 it is: no conversion back), one
+            // v_cvt_pk_f16_f32 rounds two of them.  The same bits as v_fma_mixlo/hi_f16 (K1w), which round the same f32 difference -- but
+            // those write half a register each and hold the vector issue for 9-10 cycles apiece where these take 4 and 5
+            // (scripts/probes/gap_cost_probe.hip): 27 cycles per four values instead of 38.  In asm: the compiler turns the C form
+            // into convert - subtract.
             const u32x4& hsrc = l < 2 ? vh01[tbv][l] : vh23[sp][tbv][l - 2];
             u32x4& dst = l < 2 ? vl01[tbv][l] : vl23[sp][tbv][l - 2];
-            // both registers of the group in one statement, lo / lo / hi / hi: the write of a register's upper half follows the write of
-            // its lower half at a distance of one instruction (no s_nop), and nothing reads the pair before the MFMAs of a later stage
+            // (one statement, conversions included: behind an asm statement the compiler puts an s_nop in front of its own next VALU
+            // instruction -- four cycles of issue each)
+            float r0, r1, r2, r3;
             uint32_t lo0, lo1;
-            asm("v_fma_mixlo_f16 %0, -%2, 1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, -%3, 1.0, %6 op_sel_hi:[1,0,0]\n\t"
-                "v_fma_mixhi_f16 %0, -%2, 1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %1, -%3, 1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                : "=&v"(lo0), "=&v"(lo1)
+            asm("v_fma_mix_f32 %2, -%6, 1.0, %8 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, -%6, 1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %4, -%7, 1.0, %10 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, -%7, 1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+                : "=&v"(lo0), "=&v"(lo1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
                 : "v"(hsrc[2 * g]), "v"(hsrc[2 * g + 1]), "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(xx[3]));
             dst[2 * g] = lo0, dst[2 * g + 1] = lo1;
         }
@@ -392,13 +399,11 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
         wks = w2;
     } while (++c < nch);
     W4_STAMP(2);
-    // the ring's last refills and the last chunk (nobody uses them: the loop's wait counts are the same in every k-step); the ring's and the
-    // pending chunk's registers are operands of the wait (kernels_wino.hip: to the compiler they are free from their last use on, and it
-    // would park epilogue values in them while the loads are still on their way)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int l = 0; l < 4; l++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[l][0]), "+v"(ring[l][1]), "+v"(ring[l][2]), "+v"(ring[l][3])::"memory");
-    asm volatile("" : "+v"(pend[0]), "+v"(pend[1]), "+v"(pend[2]), "+v"(pend[3]), "+v"(pend[4]), "+v"(pend[5]), "+v"(pend[6]), "+v"(pend[7]));
+    // The ring's last refills and the last chunk are on their way and nobody will use them (the loop's wait counts are the same in every
+    // k-step).  Their registers stay what they are -- operands of the wait that stands behind the exchange writes below, some 3,500 cycles
+    // from here: by then they have landed, where a wait at this point cost 1,500 cycles per layer.  (To the compiler the registers are free
+    // from their last use on; as operands of that statement they are not, and it cannot park epilogue values in them while loads are
+    // still in flight: kernels_wino.hip.)
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue ----
@@ -406,19 +411,25 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     asm volatile("" : "+v"(elane));
     const int en = elane & 31, eh = elane >> 5;
     const int board = elane >> 4, pc = elane & 15;  // final layout: lane = (board, couts 4 pc .. 4 pc + 3) of one pixel position
-    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(bias + cout0 + pc * 4);
-    const f32x4 ds4 = *reinterpret_cast<const f32x4*>(bias + cout + cout0 + pc * 4);
-    // wave q finishes tile row q of every board: pixel q * 16 + k of a board for k = 0..15 (y = 2 q + (k >> 3), x = k & 7)
+    // (global address space spelled out: in the tower kernel the layer's pointers come out of a table in memory, the compiler takes them
+    // for generic ones and its flat loads are followed by a wait for the LDS counter)
+    typedef const __attribute__((address_space(1))) f32x4 w4_gf32x4;
+    const f32x4 bias4 = *(w4_gf32x4*)(bias + cout0 + pc * 4);
+    const f32x4 ds4 = *(w4_gf32x4*)(bias + cout + cout0 + pc * 4);
+    // wave q finishes tile row q of every board: pixel q * 16 + k of a board for k = 0..15 (y = 2 q + (k >> 3), x = k & 7).  Row k of
+    // this lane = the workgroup's base (scalar) + a 32-bit lane offset that grows by one row per k: one addition per load / store
     const size_t orow = (size_t)row0 + board * 64 + q * 16;
+    const uint32_t cstride = (uint32_t)cout * 4;
+    const uint32_t evoff = (uint32_t)((board * 64 + q * 16) * cout + pc * 4) * 4;
+    const char* rbase = reinterpret_cast<const char*>(res + (size_t)row0 * cout + cout0);
+    char* obase = reinterpret_cast<char*>(out + (size_t)row0 * cout + cout0);
+    // the 16 skip rows of this lane: one load in front of each of the 16 groups of the exchange below -- issued in one burst they
+    // cost the wave ~70 cycles apiece (four waves' 64 KiB through the CU's one address unit), between the groups' VALU work a slot each
     f32x4 skip[16];
-    if (has_res) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float* sp = res + (orow + k) * (size_t)cout + cout0 + pc * 4;
-            if (PERSIST) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(skip[k]) : "v"(sp) : "memory");
-            else skip[k] = *reinterpret_cast<const f32x4*>(sp);
-        }
-    }
+    auto load_skip = [&](int k) __attribute__((always_inline)) {
+        if (PERSIST) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(skip[k]) : "v"(evoff + k * cstride), "s"(rbase) : "memory");
+        else skip[k] = *reinterpret_cast<const f32x4*>(res + (orow + k) * (size_t)cout + cout0 + pc * 4);
+    };
     W4_STAMP(3);
     asm volatile("s_barrier" ::: "memory");  // every wave has left the chunk buffers (no LDS read of the loop is outstanding: they fed VALU work long done)
     // Z[q][c'] = (row q of M) A: Z[.][0] = M[q][0] + M[q][1] + M[q][2], Z[.][1] = M[q][1] - M[q][2] - M[q][3] (K1w's order), four
@@ -430,6 +441,7 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
         for (int cb = 0; cb < 2; cb++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
+                if (has_res) load_skip(tbv * 8 + cb * 4 + g);
                 f32x4 m[4];
 #pragma unroll
                 for (int l = 0; l < 4; l++)
@@ -441,12 +453,18 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
                 *reinterpret_cast<f32x4*>(zp) = z0;
                 *reinterpret_cast<f32x4*>(zp + 64 * 256) = z1;
             }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (PERSIST && has_res) {  // the asm skip loads (the compiler does not count them)
-        asm volatile("s_waitcnt vmcnt(0)"
+    // the loop's leftover loads (above) and the asm skip loads (the compiler does not count either)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[0][2]), "+v"(ring[0][3]), "+v"(ring[1][0]), "+v"(ring[1][1]), "+v"(ring[1][2]),
+                   "+v"(ring[1][3]), "+v"(ring[2][0]), "+v"(ring[2][1]), "+v"(ring[2][2]), "+v"(ring[2][3]), "+v"(ring[3][0]), "+v"(ring[3][1]),
+                   "+v"(ring[3][2]), "+v"(ring[3][3]), "+v"(pend[0]), "+v"(pend[1]), "+v"(pend[2]), "+v"(pend[3]), "+v"(pend[4]), "+v"(pend[5]),
+                   "+v"(pend[6]), "+v"(pend[7])::"memory");
+    if (PERSIST && has_res) {
+        asm volatile(""
                      : "+v"(skip[0]), "+v"(skip[1]), "+v"(skip[2]), "+v"(skip[3]), "+v"(skip[4]), "+v"(skip[5]), "+v"(skip[6]), "+v"(skip[7]), "+v"(skip[8]),
                        "+v"(skip[9]), "+v"(skip[10]), "+v"(skip[11]), "+v"(skip[12]), "+v"(skip[13]), "+v"(skip[14]), "+v"(skip[15]));
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     W4_STAMP(4);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -466,7 +484,6 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
             v[j] = x < WINO_ACT_MAX ? x : WINO_ACT_MAX;  // the next layer's transform relies on it
         }
         vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-        float* op = out + (orow + k) * (size_t)cout + cout0 + pc * 4;
         // PERSIST: written through (sc1), every 128-byte line whole by this one instruction -- what the next layer's sc1 loads on other CUs
         // may read once this workgroup has counted itself in.  Else plain stores: the rows are read again by the four cout-group workgroups
         // of this board group in the next launch, which run on this XCD (the block-index map) -- left in its L2 they cost 0.4 us per launch
@@ -474,8 +491,8 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
         // (the s_nop: a store of more than 8 bytes reads its data registers a cycle or two after it issues, and gfx940 wants two wait
         // states before a VALU instruction overwrites them -- the compiler pads its own stores, it cannot see into this one: without it
         // the next pixel's values, computed into the same registers, went out with this pixel's address)
-        if (PERSIST) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(op), "v"(v) : "memory");
-        else *reinterpret_cast<f32x4*>(op) = v;
+        if (PERSIST) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(evoff + k * cstride), "v"(v), "s"(obase) : "memory");
+        else *reinterpret_cast<f32x4*>(out + (orow + k) * (size_t)cout + cout0 + pc * 4) = v;
     }
     if (vmax >= WINO_ACT_MAX) atomicAdd(sat, 1u);  // an activation reached the cap somewhere in this thread's share
     if (PERSIST) {

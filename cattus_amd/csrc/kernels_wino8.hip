@@ -198,10 +198,12 @@ __global__ void __launch_bounds__(512, 2)
                     const w8_f16x2 h0 = __builtin_convertvector(__builtin_shufflevector(xx, xx, 0, 1), w8_f16x2);
                     const w8_f16x2 h1 = __builtin_convertvector(__builtin_shufflevector(xx, xx, 2, 3), w8_f16x2);
                     const uint32_t hu0 = __builtin_bit_cast(uint32_t, h0), hu1 = __builtin_bit_cast(uint32_t, h1);
-                    uint32_t lo0, lo1;  // lo = f16(x - hi): kernels_wino4.hip
-                    asm("v_fma_mixlo_f16 %0, -%2, 1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, -%3, 1.0, %6 op_sel_hi:[1,0,0]\n\t"
-                        "v_fma_mixhi_f16 %0, -%2, 1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %1, -%3, 1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                        : "=&v"(lo0), "=&v"(lo1)
+                    uint32_t lo0, lo1;  // lo = f16(x - hi) as v_fma_mix_f32 + v_cvt_pk_f16_f32: kernels_wino4.hip (the bits of v_fma_mixlo/hi_f16, a third cheaper to issue)
+                    float r0, r1, r2, r3;
+                    asm("v_fma_mix_f32 %2, -%6, 1.0, %8 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, -%6, 1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                        "v_fma_mix_f32 %4, -%7, 1.0, %10 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, -%7, 1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                        "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+                        : "=&v"(lo0), "=&v"(lo1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
                         : "v"(hu0), "v"(hu1), "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(xx[3]));
                     vh[tbv][j][2 * g] = hu0, vh[tbv][j][2 * g + 1] = hu1;
                     vl[tbv][j][2 * g] = lo0, vl[tbv][j][2 * g + 1] = lo1;

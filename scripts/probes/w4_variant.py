@@ -63,7 +63,7 @@ def main():
         obj = src.with_suffix(".o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "-c", str(src), "-o", str(obj)])
         objs = [str(obj) if s == "kernels_wino4" else str(ROOT / "cattus_amd" / "build" / "hip" / f"{s}.o")
-                for s in ("kernels", "kernels_t64s", "kernels_wino", "kernels_wino4", "evaluator")]
+                for s in ("kernels", "kernels_t64s", "kernels_wino", "kernels_wino4", "kernels_wino8", "evaluator")]
         lib = ROOT / "cattus_amd" / f"libcattus_hip_w4_{name.replace('+', '_')}.so"
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", str(lib), *objs, "-lpthread", "-ldl"])
         print("built", lib)
