@@ -111,20 +111,23 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     // the four U stages of a k-step are 2 KiB apart: l = 0, 1 as immediate offsets from the k-step's base, l = 2, 3 through a second
     // lane offset 4 KiB further (one base pointer per k-step and cout block: every scalar addition in this loop costs the wave an
     // issue slot that nothing hides)
-#define W4_ULOAD(OFF)                                                                                                                      \
-    asm volatile("global_load_dwordx4 %0, %4, %5 offset:" #OFF "\n\tglobal_load_dwordx4 %1, %4, %5 offset:" #OFF "+1024\n\t"             \
-                 "global_load_dwordx4 %2, %4, %6 offset:" #OFF "\n\tglobal_load_dwordx4 %3, %4, %6 offset:" #OFF "+1024"                  \
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)                                                                                  \
-                 : "v"(voff), "s"(p0), "s"(p1)                                                                                             \
-                 : "memory")
-    auto load_ustage = [&](u32x4(&slot)[4], const char* pk, int l) __attribute__((always_inline)) {  // pk: the k-step's U (this wave's frequency row)
-        const char* p0 = pk;
-        const char* p1 = pk + wcb;
+    // One load of a U stage: j = 0..3 = [cb0 hi, cb0 lo, cb1 hi, cb1 lo].  In the loop a stage's four loads go out ONE PER MFMA GAP: four
+    // in a row cost the wave ~21 cycles apiece (the CU's address unit takes a 1 KiB wave-load per 16 cycles, from all four waves), one
+    // per gap ~14 (scripts/probes/gap_cost_probe.hip, modes 41-43)
+    auto load_u1 = [&](u32x4& reg, const char* pk, int l, int j) __attribute__((always_inline)) {  // pk: the k-step's U (this wave's frequency row)
+        const char* pj = j >> 1 ? pk + wcb : pk;
         const uint32_t voff = l >> 1 ? voff1 : voff0;
-        u32x4 a, b, c, d;
-        if (l & 1) W4_ULOAD(2048);
-        else W4_ULOAD(0);
-        slot[0] = a, slot[1] = b, slot[2] = c, slot[3] = d;
+        const int imm = (l & 1) * 2048 + (j & 1) * 1024;
+        u32x4 r;
+        if (imm == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(voff), "s"(pj) : "memory");
+        else if (imm == 1024) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(r) : "v"(voff), "s"(pj) : "memory");
+        else if (imm == 2048) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(r) : "v"(voff), "s"(pj) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(r) : "v"(voff), "s"(pj) : "memory");
+        reg = r;
+    };
+    auto load_ustage = [&](u32x4(&slot)[4], const char* pk, int l) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) load_u1(slot[j], pk, l, j);
     };
 
     // ---- activation chunks: global -> registers -> LDS.  (LDS-DMA first: 10 pieces of 1 KiB per wave and chunk cost the issuing wave
@@ -136,15 +139,16 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     const uint32_t aoff = (uint32_t)(tid >> 3) * row_bytes + (tid & 7) * 16;
     const uint32_t wdst = (uint32_t)(q * W4_RP + ((tid >> 3) & 7) * SP + (tid & 7) * 16);  // pixel row 32 i + (t >> 3) = board row 4 i + q, column (t >> 3) & 7
     constexpr int W4_NP = 8;  // loads per thread and chunk: they count in vmcnt like the ring's
+    auto load_piece = [&](u32x4& reg, int ch, int i) __attribute__((always_inline)) {
+        const char* src = abase0 + (size_t)ch * 128 + (size_t)i * 32 * row_bytes;
+        u32x4 r;
+        if (PERSIST) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(r) : "v"(aoff), "s"(src) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(aoff), "s"(src) : "memory");
+        reg = r;
+    };
     auto load_chunk = [&](u32x4(&regs)[W4_NP], int ch) __attribute__((always_inline)) {
-        const char* src = abase0 + (size_t)ch * 128;
 #pragma unroll
-        for (int i = 0; i < W4_NP; i++) {
-            u32x4 r;
-            if (PERSIST) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(r) : "v"(aoff), "s"(src + (size_t)i * 32 * row_bytes) : "memory");
-            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(aoff), "s"(src + (size_t)i * 32 * row_bytes) : "memory");
-            regs[i] = r;
-        }
+        for (int i = 0; i < W4_NP; i++) load_piece(regs[i], ch, i);
     };
     auto store_piece = [&](const u32x4(&regs)[W4_NP], uint32_t dbuf_plus_wdst, int i) __attribute__((always_inline)) {
         // board row 4 i + q of the workgroup's 32: tile block i >> 2, board (i >> 1) & 1 of it, row 4 (i & 1) + q of that board
@@ -154,10 +158,10 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     for (int i = tid; i < 4 * (W4_ZAREA / 16); i += 256)  // the four zero areas
         reinterpret_cast<f32x4*>(smem + (i / (W4_ZAREA / 16)) * W4_IMGZ + W4_IMG)[i % (W4_ZAREA / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
     // The ring's l = 0, 1 first -- the weights do not depend on anybody --, then (PERSIST) the wait for the board group's producers of the
-    // previous layer, then chunk 0, chunk 1 and the ring's l = 2, 3: the order of the steady state, where a chunk goes out in stage 4 of
-    // the odd k-step between the refills of l = 0, 1 and of l = 2, 3 -- the counted waits of k-step 0 are then those of every even k-step
-    // (scripts/audit_inflight_regs.py caught the one order in which they were not).  `pend` holds the chunk on its way throughout the
-    // loop: written to the freed buffer in stage 4 of the even k-step
+    // previous layer, then chunk 0, chunk 1 and the ring's l = 2: the ORDER of the steady state (per k-step: l = 0 in stage 3, l = 1 in
+    // stage 4, the odd k-step's chunk in stages 5-6, l = 2 in stage 7, l = 3 in the next k-step's stage 0 -- k-step 0 fetches its own), so
+    // that the counted waits of k-step 0 are those of every even k-step (scripts/audit_inflight_regs.py caught the one order in which
+    // they were not).  `pend` holds the chunk on its way throughout the loop: written to the freed buffer in stage 4 of the even k-step
     u32x4 first[W4_NP], pend[W4_NP];
     const char* wks = wb0;  // U of the k-step being multiplied
     load_ustage(ring[0], wks, 0);
@@ -187,7 +191,6 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     load_chunk(first, 0);
     load_chunk(pend, 1);  // cin >= 128: at least four chunks
     load_ustage(ring[2], wks, 2);
-    load_ustage(ring[3], wks, 3);
 
     // ---- the transform's geometry: lane = (tile n of the tile block, k-half hh): board n >> 4, tile row (n >> 2) & 3, column n & 3 ----
     // Wave q combines the patch rows (ra, rb) of its tile: q = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 (B^T row q), as
@@ -291,11 +294,11 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[l][t2][c][e] = 0.0f;
 
-    // ---- prologue: chunk 0 has landed (everything but chunk 1's 8 loads and the ring's last 8) and goes to buffer 0; the rows of the first
+    // ---- prologue: chunk 0 has landed (everything but chunk 1's 8 loads and the ring's last 4) and goes to buffer 0; the rows of the first
     // group, phase (0, tb0) whole, the first half of phase (0, tb1) -- its second half sits in stages 0, 1 of k-step 0, as in every k-step ----
     asm volatile("s_waitcnt vmcnt(%8)"
                  : "+v"(first[0]), "+v"(first[1]), "+v"(first[2]), "+v"(first[3]), "+v"(first[4]), "+v"(first[5]), "+v"(first[6]), "+v"(first[7])
-                 : "n"(W4_NP + 8));  // all but chunk 1 and the ring's l = 2, 3
+                 : "n"(W4_NP + 4));  // all but chunk 1 and the ring's l = 2
 #pragma unroll
     for (int i = 0; i < W4_NP; i++) store_piece(first, wdst, i);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -307,9 +310,13 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     for (int j = 0; j < 12; j++) slot(0, 1, j);
 
     // One k-step: 8 stages of 6 MFMAs; SP_ = parity of the k-step (compile time), which fixes the l = 2,3 set, the chunk half the
-    // slices read and the wait counts.  `wnext`: U of the next k-step (clamped to the last: nobody uses those refills).
+    // slices read and the wait counts.  `wcur` / `wnext`: U of this and of the next k-step (clamped to the last: nobody uses those refills).
     // LAST: the layer's last k-step -- nothing left to fetch, refill or transform, no chunk change.
-    auto kstep = [&](const char* wnext, int ch_next, auto sp_tag, auto last_tag) __attribute__((always_inline)) {
+    // The loads, ONE PER GAP (even stages: gaps 2-5, beside the slices' reads and conversions; odd stages: gaps 0-3), in the order
+    //   stage 0: l = 3 of THIS k-step (its slot was last used in stage 7 of the one before)   stage 3: l = 0 of the next k-step
+    //   stage 4: l = 1 of the next    stages 5, 6 (odd k-step): the chunk's 8 pieces           stage 7: l = 2 of the next
+    // A U stage's loads are 5 stages (~1,500 cycles) ahead of its first use, a chunk 6 1/2 ahead of its stores.
+    auto kstep = [&](const char* wcur, const char* wnext, int ch_next, auto sp_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr int SP_ = decltype(sp_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value != 0;
 #pragma unroll
@@ -328,31 +335,20 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
                     for (int k = 0; k < 3; k++) cur[X][k] += bufstep;
                 bufstep = -bufstep;
             }
-            if (i == 4 && SP_ == 1 && !LAST) {
-                // chunk c + 2 into registers, BEHIND the refills of l = 0, 1: loads complete in order, these come from far away (the
-                // previous layer's non-temporal stores), and the first ring stage that has to wait for them is l = 2 of the next
-                // k-step, nine stages from here (issued at the chunk change it was l = 0, six stages away: ~600 cycles stalled per chunk)
-                load_chunk(pend, ch_next);
-            }
             if (first_use) {
                 constexpr int NP = W4_NP;
                 u32x4 r0 = ring[l][0], r1 = ring[l][1], r2 = ring[l][2], r3 = ring[l][3];
-                // younger than this U stage: the refills of the slots freed since (l = 0: l = 1, 2, 3 of this k-step; l = 1: 2, 3; l = 2: 3 and the
-                // next k-step's 0, 1; l = 3: those two) and the chunk's W4_NP loads where they went out in between (odd k-step, stage 4:
-                // behind the next k-step's l = 0, 1, ahead of its 2, 3)
-                if (l == 0 && SP_ == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + NP));
-                else if (l == 0) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-                else if (l == 1 && SP_ == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + NP));
-                else if (l == 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                // younger than this U stage in the queue (see the order above): l = 0: l = 1, [the chunk], l = 2; l = 1: [the chunk], l = 2, 3;
+                // l = 2: l = 3 and the next k-step's l = 0; l = 3: the next k-step's l = 0, 1 -- eight loads, and the chunk's W4_NP in front
+                // of the even k-step's l = 0, 1 (it went out in stages 5, 6 of the odd k-step before)
+                if (l < 2 && SP_ == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + NP));
                 else if (l == 2 && SP_ == 0) {
                     // the even k-step's l = 2 is the first stage younger than the chunk loaded in the odd k-step before: its registers are
                     // operands of this wait, and the stores into the freed buffer follow it (this stage's gaps)
-                    asm volatile("s_waitcnt vmcnt(12)"
+                    asm volatile("s_waitcnt vmcnt(8)"
                                  : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(pend[0]), "+v"(pend[1]), "+v"(pend[2]), "+v"(pend[3]), "+v"(pend[4]),
                                    "+v"(pend[5]), "+v"(pend[6]), "+v"(pend[7]));
-                } else if (l == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(12 + NP));
-                else if (SP_ == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-                else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(8 + NP));
+                } else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
                 ring[l][0] = r0, ring[l][1] = r1, ring[l][2] = r2, ring[l][3] = r3;
             }
             const frag uh0 = __builtin_bit_cast(frag, ring[l][0]), ul0 = __builtin_bit_cast(frag, ring[l][1]);
@@ -371,6 +367,18 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
                     store_piece(pend, target, 2 * e);
                     store_piece(pend, target, 2 * e + 1);
                 }
+                // this gap's load
+                const int le = (i & 1) ? e : e - 2;
+                if (le >= 0 && le < 4) {
+                    if (i == 0) load_u1(ring[3][le], wcur, 3, le);
+                    if (i == 3 && !LAST) load_u1(ring[0][le], wnext, 0, le);
+                    if (i == 4 && !LAST) load_u1(ring[1][le], wnext, 1, le);
+                    if (i == 7 && !LAST) load_u1(ring[2][le], wnext, 2, le);
+                }
+                if (SP_ == 1 && !LAST) {
+                    if (i == 5) load_piece(pend[e], ch_next, e);
+                    if (i == 6 && (e == 2 || e == 3)) load_piece(pend[4 + e], ch_next, 4 + e);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             };
             Mfma<T>::mac(ul0, vh, acc[l][tbv][0]);
@@ -385,7 +393,6 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
             gap(4);
             Mfma<T>::mac(uh1, vh, acc[l][tbv][1]);
             gap(5);
-            if (!first_use && !LAST) load_ustage(ring[l], wnext, l);  // the slot is free: the next k-step's stage
         }
     };
     W4_STAMP(1);
@@ -394,8 +401,8 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
           // path that skips it -- 32 registers, spilled in the tower kernel)
         const char* w1 = wks + (size_t)16 * SW_STAGE;                       // k-step 2c + 1
         const char* w2 = wks + (size_t)(c + 1 < nch ? 32 : 16) * SW_STAGE;  // k-step 2c + 2, or the last one again
-        kstep(w1, 0, w4_int<0>{}, w4_int<0>{});
-        kstep(w2, min(c + 2, nch - 1), w4_int<1>{}, w4_int<0>{});  // the chunk change inside fetches chunk c + 2 (or the last one again: nobody reads it)
+        kstep(wks, w1, 0, w4_int<0>{}, w4_int<0>{});
+        kstep(w1, w2, min(c + 2, nch - 1), w4_int<1>{}, w4_int<0>{});  // fetches chunk c + 2 (or the last one again: nobody reads it)
         wks = w2;
     } while (++c < nch);
     W4_STAMP(2);

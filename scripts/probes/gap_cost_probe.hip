@@ -91,12 +91,12 @@ __device__ __forceinline__ void filler(Regs& r, float sg, unsigned lds_addr, uns
     } else if constexpr (MODE == 13) {  // 4 v_fma + one global load in 5 of 12 gaps (the kernel's 20 per 48)
         FMA1(0); FMA1(1); FMA1(2); FMA1(3);
         if (j == 1 || j == 3 || j == 5 || j == 7 || j == 9) GL1(j >> 1);
-        if (j == 11) WAITVM;
+        if (j == 11) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     } else if constexpr (MODE == 14) {  // 4 v_fma, 4 global loads in one gap + 1 in another
         FMA1(0); FMA1(1); FMA1(2); FMA1(3);
         if (j == 5) { GL1(0); GL1(1); GL1(2); GL1(3); }
         if (j == 9) GL1(0);
-        if (j == 11) WAITVM;
+        if (j == 11) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     } else if constexpr (MODE == 15) {  // 4 v_fma + 2 SALU + s_nop
         FMA1(0); FMA1(1); FMA1(2); FMA1(3); SALU1; SALU1; NOP4;
     } else if constexpr (MODE == 16) {  // 4 v_fma + 2 SALU
@@ -143,6 +143,35 @@ __device__ __forceinline__ void filler(Regs& r, float sg, unsigned lds_addr, uns
         if constexpr (MODE == 37) { I35(0); I35(1); I35(2); I35(3); I35(4); I35(5); I35(6); I35(7); }   // 8 independent v_sub
         if constexpr (MODE == 38) { I20(0); I20(1); I20(2); I20(3); I22(0); I22(1); I22(2); I22(3); }   // 4 cvt_pk + 4 mix_f32
         if constexpr (MODE == 39) { RD1(0); RD1(1); if (j == 11) WAITLDS; }                             // 2 ds_read_b128, nothing else
+    } else if constexpr (MODE >= 40 && MODE < 50) {
+        // the kernel's pattern with the lo half as v_fma_mix_f32 + v_cvt_pk_f16_f32, and its 5 global loads per 12 gaps
+        // (16 ring + 4 chunk loads per 48): 40 none, 41 a burst of four + one, 42 one per gap in five light gaps, 43 one per gap in gaps 5-9
+        if (j < 2) {
+            WAITLDS;
+            FMA1(0); FMA1(1); FMA1(2); FMA1(3); FMA1(4); FMA1(5); FMA1(6); FMA1(7);
+        } else if (j < 4) {
+            RD1(4 * (j - 2)); RD1(4 * (j - 2) + 1); RD1(4 * (j - 2) + 2); RD1(4 * (j - 2) + 3);
+        } else if ((j & 1) == 0) {
+            SUB1(0); SUB1(1); SUB1(2); SUB1(3); CVT1(0); CVT1(1);
+        } else {
+            I22(0); I22(1); I22(2); I22(3); I20(2); I20(3);
+        }
+        if constexpr (MODE == 41) {
+            if (j == 5) { GL1(0); GL1(1); GL1(2); GL1(3); }
+            if (j == 9) GL1(0);
+        }
+        if constexpr (MODE == 42) {
+            if (j == 2 || j == 3 || j == 5 || j == 7 || j == 9) GL1(j >> 1);
+        }
+        if constexpr (MODE == 43) {
+            if (j >= 5 && j <= 9) GL1(j);
+        }
+        if constexpr (MODE == 44) {  // two bursts of two + one
+            if (j == 5 || j == 9) { GL1(0); GL1(1); }
+            if (j == 11) GL1(2);
+        }
+        // (two rounds of loads stay in flight, as in the kernel's ring: the wait is for loads issued 24-36 gaps ago)
+        if (MODE != 40 && j == 11) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     } else if constexpr (MODE == 18) {  // 6 plain v_add (the guide's filler)
         asm volatile("v_add_f32 %0, %1, %0" : "+v"(r.x[0]) : "v"(r.y[0]));
         asm volatile("v_add_f32 %0, %1, %0" : "+v"(r.x[1]) : "v"(r.y[1]));
@@ -201,6 +230,47 @@ __global__ void __launch_bounds__(256, 1) probe(const char* gsrc, float* sink, u
     if (lane == 0) cycles[blockIdx.x * 4 + q] = t1 - t0;
 }
 
+// What a CU takes in from a set its XCD's L2 holds, by how many CUs ask at once: four waves per CU, each streaming its own 256 KiB
+// (global_load_dwordx4, 1 KiB per instruction, 8 in flight per wave), `blocks` workgroups (one per CU while blocks <= 256).
+__global__ void __launch_bounds__(256, 1) stream_probe(const char* gsrc, float* sink, unsigned long long* cycles, int rounds, int shared) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned goff = lane * 16;
+    // shared = 1: every CU reads the same 1 MiB (4 waves x 256 KiB); 0: its own 1 MiB of a 4 MiB set (the blocks of one cout group share)
+    const char* gbase = gsrc + ((size_t)(shared ? 0 : (blockIdx.x & 3)) * 4 + q) * 262144;
+    u4 r[8];
+    for (int i = 0; i < 8; i++) r[i] = u4{0, 0, 0, 0};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < rounds; it++) {
+        const char* p = gbase + (size_t)(it & 31) * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[i]) : "v"(goff), "s"(p + i * 1024) : "memory");
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 8; i++) s += (float)r[i][0] + (float)r[i][3];
+    sink[blockIdx.x * 256 + tid] = s;
+    if (lane == 0) cycles[blockIdx.x * 4 + q] = t1 - t0;
+}
+
+static void run_stream(const char* gsrc, float* sink, unsigned long long* cyc, int blocks, int shared) {
+    const int rounds = 512;
+    std::vector<unsigned long long> h(blocks * 4);
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL(stream_probe, dim3(blocks), dim3(256), 98304, 0, gsrc, sink, cyc, rounds, shared);
+        hipDeviceSynchronize();
+        hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+        std::sort(h.begin(), h.end());
+        best = std::min(best, (double)h[h.size() / 2]);
+    }
+    std::printf("stream: %3d workgroups, %s: %6.1f B/clk per CU (4 waves x %d KiB in %.0f cycles)\n", blocks, shared ? "one 1 MiB set for all" : "1 MiB of a 4 MiB set ",
+                4.0 * rounds * 8192 / best, rounds * 8, best);
+}
+
 template <int MODE>
 static void run(const char* name, const char* gsrc, float* sink, unsigned long long* cyc, int blocks) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
@@ -225,6 +295,9 @@ int main() {
     hipMemset(gsrc, 0, (size_t)blocks * 4 * 4096 * 64 + 8192);
     hipMalloc(&sink, blocks * 256 * 4);
     hipMalloc(&cyc, blocks * 4 * 8);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    for (int shared = 0; shared < 2; shared++)
+        for (int b : {256, 128, 64, 32, 8}) run_stream(gsrc, sink, cyc, b, shared);
     run<0>("bare MFMAs", gsrc, sink, cyc, blocks);
     run<18>("6 v_add_f32", gsrc, sink, cyc, blocks);
     run<1>("4 v_fma_f32 (SGPR operand)", gsrc, sink, cyc, blocks);
@@ -260,6 +333,11 @@ int main() {
     run<31>("4 v_pack_b32_f16", gsrc, sink, cyc, blocks);
     run<32>("4 ds_read_b64", gsrc, sink, cyc, blocks);
     run<39>("2 ds_read_b128", gsrc, sink, cyc, blocks);
+    run<40>("new pattern (8,8,4r,4r,6,6,...), no global loads", gsrc, sink, cyc, blocks);
+    run<41>("new pattern + 5 global loads per 12 gaps: 4 in one gap, 1 in another", gsrc, sink, cyc, blocks);
+    run<44>("new pattern + 5 global loads: 2 + 2 + 1", gsrc, sink, cyc, blocks);
+    run<42>("new pattern + 5 global loads: one per gap (gaps 2,3,5,7,9)", gsrc, sink, cyc, blocks);
+    run<43>("new pattern + 5 global loads: one per gap (gaps 5-9)", gsrc, sink, cyc, blocks);
     run<7>("the kernel's pattern without its reads (8,8,0,0,6,4,6,4,6,4,6,4)", gsrc, sink, cyc, blocks);
     run<5>("the kernel's pattern (8,8,4r,4r,6,4,6,4,6,4,6,4)", gsrc, sink, cyc, blocks);
     run<8>("balanced pattern without reads (4,5x8,4,4,4)", gsrc, sink, cyc, blocks);

@@ -16,6 +16,9 @@ ROOT = Path(__file__).resolve().parent.parent.parent
 SRC = ROOT / "cattus_amd" / "csrc" / "kernels_wino4.hip"
 OUT = Path("/tmp/variants")
 
+SKEW_ANCHOR = """                asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int X = 0; X < 2; X++)"""
 EDITS = {
     "notransform": [("                slot(ph == 1 ? SP_ : SP_ ^ 1, ph == 2 ? 0 : 1, j);\n", "")],
     "noreads": [("            if (jj == 2) read_row(pa, 0, ntb, nsp, ng);\n            else read_row(pb, 1, ntb, nsp, ng);\n", "")],
@@ -24,6 +27,11 @@ EDITS = {
     "nomfma": [("            Mfma<T>::mac(ul0, vh, acc[l][tbv][0]);\n", ""), ("            Mfma<T>::mac(ul1, vh, acc[l][tbv][1]);\n", ""),
                ("            Mfma<T>::mac(uh0, vl, acc[l][tbv][0]);\n", ""), ("            Mfma<T>::mac(uh1, vl, acc[l][tbv][1]);\n", ""),
                ("            Mfma<T>::mac(uh0, vh, acc[l][tbv][0]);\n", ""), ("            Mfma<T>::mac(uh1, vh, acc[l][tbv][1]);\n", "")],
+    # behind the chunk barrier wave q waits q x N cycles: the four waves' load bursts (4 x 16 cycles of the CU's address unit each) then go
+    # out one after the other instead of at the same moment (results stay right)
+    "skew64": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) __builtin_amdgcn_s_sleep(1);\n                if (q >= 2) __builtin_amdgcn_s_sleep(1);\n                if (q >= 3) __builtin_amdgcn_s_sleep(1);\n#pragma unroll", 1))],
+    "skew32": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n                if (q >= 2) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n                if (q >= 3) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n#pragma unroll", 1))],
+    "skew128": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) __builtin_amdgcn_s_sleep(2);\n                if (q >= 2) __builtin_amdgcn_s_sleep(2);\n                if (q >= 3) __builtin_amdgcn_s_sleep(2);\n#pragma unroll", 1))],
     "nodma": [("                issue_chunk(ch_next, freed);\n", "")],
     "noepi": [("    asm volatile(\"s_barrier\" ::: \"memory\");  // every wave has left the chunk buffers", "    if (cin > 0) return;\n    asm volatile(\"s_barrier\" ::: \"memory\");  // every wave has left the chunk buffers")],
     # the one-launch tower with one of its sc1 / asm pieces replaced by the per-layer kernel's plain form (results may stay right)
