@@ -204,6 +204,7 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     const float sg = q == 1 ? 1.0f : -1.0f;  // wave-uniform: an SGPR operand of the asm fma below
     uint32_t cur[2][3];
     {
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;  // the workgroup's LDS base (0 here: an add the compiler cannot fold)
         const int tbase = ((b2 * 8 + 2 * ty - 1) * W4_RP) + (2 * tx - 1) * SP + b2 * 16 + hh * 32;
         const int tdelta = tbase - W4_IMG;
         const int mra = (ra == 0 && ty == 0) ? 255 : -1, mrb = (rb == 3 && ty == 3) ? 255 : -1;
@@ -211,9 +212,9 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
 #pragma unroll
         for (int X = 0; X < 2; X++) {
             const int mr = X ? mrb : mra, rr = X ? rb : ra;
-            cur[X][0] = (uint32_t)(W4_IMG + (tdelta & mr & mc0) + rr * W4_RP);
-            cur[X][1] = (uint32_t)(W4_IMG + (tdelta & mr) + rr * W4_RP + SP);
-            cur[X][2] = (uint32_t)(W4_IMG + (tdelta & mr & mc3) + rr * W4_RP + 3 * SP);
+            cur[X][0] = lds0 + (uint32_t)(W4_IMG + (tdelta & mr & mc0) + rr * W4_RP);
+            cur[X][1] = lds0 + (uint32_t)(W4_IMG + (tdelta & mr) + rr * W4_RP + SP);
+            cur[X][2] = lds0 + (uint32_t)(W4_IMG + (tdelta & mr & mc3) + rr * W4_RP + 3 * SP);
         }
     }
     int bufstep = W4_DBUF;  // cur[] += bufstep at every chunk change, bufstep = -bufstep
@@ -259,10 +260,12 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     };
     auto read_row = [&](f32x4(&dstv)[4], int X, int tbv, int kp, int g) __attribute__((always_inline)) {
         const int imm = tbv * W4_IMGZ + kp * 64 + g * 16;
-        dstv[0] = *reinterpret_cast<const f32x4*>(smem + cur[X][0] + imm);
-        dstv[1] = *reinterpret_cast<const f32x4*>(smem + cur[X][1] + imm);
-        dstv[2] = *reinterpret_cast<const f32x4*>(smem + cur[X][1] + imm + SP);
-        dstv[3] = *reinterpret_cast<const f32x4*>(smem + cur[X][2] + imm);
+        // (cur[] are LDS addresses, the workgroup's base included: as `smem + offset` every read pair paid a v_add of the base)
+        typedef const __attribute__((address_space(3))) f32x4 w4_lf32x4;
+        dstv[0] = *(w4_lf32x4*)(uintptr_t)(cur[X][0] + imm);
+        dstv[1] = *(w4_lf32x4*)(uintptr_t)(cur[X][1] + imm);
+        dstv[2] = *(w4_lf32x4*)(uintptr_t)(cur[X][1] + imm + SP);
+        dstv[3] = *(w4_lf32x4*)(uintptr_t)(cur[X][2] + imm);
     };
     // slot j of phase (sp = parity of the target k-step, tbv).  A group's twelve slots: 0, 1 combine its patch rows (read ten slots
     // earlier: an LDS read that four waves issue at once takes ~200 cycles to come back, and a wave that waits for it stops issuing
@@ -270,6 +273,10 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     auto slot = [&](int sp, int tbv, int j) __attribute__((always_inline)) {
         const int g = j / 12, jj = j % 12;
         if (jj < 2) {
+            // (the group's eight reads were issued ten slots ago: as operands of one empty statement they are waited for once -- the
+            // compiler would count them down read by read, four s_waitcnt per group, an issue slot each)
+            if (jj == 0)
+                asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
 #pragma unroll
             for (int c = 2 * jj; c < 2 * jj + 2; c++)
 #pragma unroll

@@ -32,6 +32,8 @@ EDITS = {
     "skew64": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) __builtin_amdgcn_s_sleep(1);\n                if (q >= 2) __builtin_amdgcn_s_sleep(1);\n                if (q >= 3) __builtin_amdgcn_s_sleep(1);\n#pragma unroll", 1))],
     "skew32": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n                if (q >= 2) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n                if (q >= 3) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n#pragma unroll", 1))],
     "skew128": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) __builtin_amdgcn_s_sleep(2);\n                if (q >= 2) __builtin_amdgcn_s_sleep(2);\n                if (q >= 3) __builtin_amdgcn_s_sleep(2);\n#pragma unroll", 1))],
+    "sleep1": [("                __builtin_amdgcn_s_sleep(8);\n", "                __builtin_amdgcn_s_sleep(1);\n")],
+    "sleep0": [("                __builtin_amdgcn_s_sleep(8);\n", "")],
     "nodma": [("                issue_chunk(ch_next, freed);\n", "")],
     "noepi": [("    asm volatile(\"s_barrier\" ::: \"memory\");  // every wave has left the chunk buffers", "    if (cin > 0) return;\n    asm volatile(\"s_barrier\" ::: \"memory\");  // every wave has left the chunk buffers")],
     # the one-launch tower with one of its sc1 / asm pieces replaced by the per-layer kernel's plain form (results may stay right)
