@@ -273,14 +273,18 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     auto slot = [&](int sp, int tbv, int j) __attribute__((always_inline)) {
         const int g = j / 12, jj = j % 12;
         if (jj < 2) {
-            // (the group's eight reads were issued ten slots ago: as operands of one empty statement they are waited for once -- the
-            // compiler would count them down read by read, four s_waitcnt per group, an issue slot each)
-            if (jj == 0)
-                asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+            // (the group's eight reads were issued ten slots ago: all of them are operands of the slot's first instruction and waited for
+            // once -- the compiler would count them down read by read, four s_waitcnt per group, an issue slot each)
 #pragma unroll
             for (int c = 2 * jj; c < 2 * jj + 2; c++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(tt[c][e]) : "v"(pb[c][e]), "s"(sg), "v"(pa[c][e]));
+                for (int e = 0; e < 4; e++) {
+                    if (jj == 0 && c == 0 && e == 0)
+                        asm("v_fma_f32 %0, %1, %2, %3"
+                            : "=v"(tt[c][e])
+                            : "v"(pb[c][e]), "s"(sg), "v"(pa[c][e]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]));
+                    else asm("v_fma_f32 %0, %1, %2, %3" : "=v"(tt[c][e]) : "v"(pb[c][e]), "s"(sg), "v"(pa[c][e]));
+                }
         } else if (jj < 4) {
             // behind (s, tb0) comes (s, tb1), behind (s, tb1) comes (s + 1, tb0)
             const int nsp = g == 0 || tbv == 0 ? sp : sp ^ 1, ntb = g == 0 ? tbv : tbv ^ 1, ng = g ^ 1;
