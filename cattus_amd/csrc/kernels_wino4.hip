@@ -14,15 +14,18 @@
 //       (ds_read_b128, 4 channels), combined in f32 (the order of K1w: rows first, then columns), split into (hi, lo) and
 //       written into the registers the MFMAs read.  No V image, no V write, no V fragment read, no barrier for V; the four waves
 //       do the same number of additions in total as K1w's shared transform (each does one row of the four).
-//   d: 32-channel chunks of the 256 pixel rows by LDS-DMA, two images per buffer (one per tile block, K1w's layout: pixel pitch
-//       144 B, 64 B per board row, zero area for off-board patch pixels, and the second board one 16-B piece to the right: with
-//       32 DIFFERENT tiles per half wave that is what keeps the four 16-lane groups of a ds_read_b128 on 16 different bank slots)
-//   per k-step (16 channels) a wave issues 48 MFMAs (as K1w), 16 global_load_dwordx4 (K1w: 32) and 32 ds_read_b128 (K1w: 32 of
-//       fragments + 16 b64 of patch + 16 writes), between which sit ~224 VALU instructions of transform (K1w: ~210)
+//   d: 32-channel chunks of the 256 pixel rows, global -> registers -> LDS (8 + 8 per thread and chunk), two images per buffer (one
+//       per tile block, K1w's layout: pixel pitch 144 B, 64 B per board row, zero area for off-board patch pixels, and the second
+//       board one 16-B piece to the right: with 32 DIFFERENT tiles per half wave that is what keeps the four 16-lane groups of a
+//       ds_read_b128 on 16 different bank slots)
+//   per k-step (16 channels) a wave issues 48 MFMAs (as K1w), 16 + 4 global_load_dwordx4 (K1w: 32) -- ONE PER MFMA GAP, never in a
+//       row -- and 32 ds_read_b128 in bursts of four, between which sit ~290 VALU instructions of transform: per V value a row
+//       combination, a column combination, half a conversion for the hi half, an f32 difference and half a conversion for the lo
+//       half (17 issue cycles; scripts/probes/gap_cost_probe.hip prices every one of them: the loop is the sum of its issue costs)
 //   stage order of a k-step: (tb0,l0) (tb0,l1) (tb1,l0) (tb1,l1) (tb0,l2) (tb0,l3) (tb1,l2) (tb1,l3): a U stage (4 loads, 16
-//       registers) lives for three stages and its ring slot has five stages (960 MFMA cycles) to refill -- a ring of ONE k-step
-//       (64 registers); V of k-step s+1 is made in 24-gap phases (tb0: stages 2-5 of k-step s, tb1: stages 6-7 and the next 0-1)
-//       into the l = 0,1 registers as they fall free and into the other of two l = 2,3 sets
+//       registers) lives for three stages, is refilled in the gaps of the stage behind its last use and has five stages to land -- a
+//       ring of ONE k-step (64 registers); V of k-step s+1 is made in 24-gap phases (tb0: stages 2-5 of k-step s, tb1: stages 6-7 and
+//       the next 0-1) into the l = 0,1 registers as they fall free and into the other of two l = 2,3 sets
 //   epilogue: Z[q][c'] = row q of M A per lane, exchanged through LDS (128 KB, XOR-swizzled), Y = A^T Z summed across the waves
 //       in K1w's order, * 2^-s + bias, + skip, ReLU, cap, whole-line f32 stores.
 // Per accumulator the MFMA sequence is K1w's (k ascending; U_lo V_hi, U_hi V_lo, U_hi V_hi), V and Y are combined in K1w's order:
