@@ -84,7 +84,7 @@ def delivery_roof(kernel: str, filters: int, rows: int, launch_us: float):
 
 DTYPE_NOTE = {
     "f16x2": "split precision: operands as pairs of f16 values (22 significant bits), three f16 MFMA terms per product, f32 accumulation, "
-             "f32 heads; inside the reference's cross-runtime tolerance (training/tests/test_net_output.py:28-33).  At batch >= 192 on 8x8 "
+             "f32 heads; inside the reference's cross-runtime tolerance (training/tests/test_net_output.py:28-33).  At batch > 128 on 8x8 "
              "boards the tower runs in Winograd F(2x2,3x3) form (roofline.kernel says which): 2.25x fewer MFMAs, same tolerance, the f32 "
              "search's visit counts in 2,048 of 2,048 searches",
     "bf16": "bf16 operands, f32 accumulation: throughput mode, 8 significant bits, outside the reference's tolerance",
@@ -351,7 +351,7 @@ def selfplay_leg(blob, dtype, local_rank, rank, world, *, games, slots, sims, ma
     threads = search_threads(sp, world)
     # model.batch_size as a user would configure it for this many concurrent games (one leaf per tree in flight: a batch can never
     # hold more than there are games, and with two batches in flight it holds well under half of them); the evaluator picks its
-    # kernels by it (the Winograd form of the f16x2 tower from 192 up, the small tiles of the direct kernels below)
+    # kernels by it (the Winograd form of the f16x2 tower above 128, the small tiles of the direct kernels up to there)
     bsz = min(batch, slots)
     with HipEvaluator(blob, batch_size=bsz, plane_words=1, dtype=dtype, device=local_rank) as ev:
         cfg = sp.make_config(sim_num=sims, batch_size=bsz, threads=threads, concurrent_games=slots, cache_size=1000000,

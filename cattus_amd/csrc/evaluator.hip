@@ -285,8 +285,10 @@ struct cattus_eval {
     int t64_force_ch = 0;          // CATTUS_T64_CH=2|4: workgroup shape of the resident tower (A/B runs, the row-split test)
     // f16x2, 8x8 boards, filters a multiple of 128: every layer behind the stem in Winograd F(2x2, 3x3) form (kernels_wino.hip).
     // Chosen once, when the evaluator is created -- never per batch, so that a leaf's result does not depend on the batch it came
-    // in: for max_batch >= 192 (below that the direct kernels' small tiles win: 14 against 33 us per launch at 64 leaves of chess
-    // 20x256, 42.8 against 37.5 at 256); CATTUS_WINOGRAD=0 / 1 forbids / forces it.
+    // in: for max_batch > 128 (up to there the direct kernels' small tiles win or tie -- whole step of chess 20x256, direct | Winograd: 0.59 |
+    // 0.89 ms at 64 leaves, 0.87 | 0.89 at 96, 0.97 | 0.90 at 128 full and ~0.87 | 0.89 at the ~93 a 128-leaf self-play batch holds; from 129 on
+    // the direct form needs a second 128-row tile: 1.45 | 0.93 at 160, 1.53 | 1.01 at 192, 1.77 | 1.25 at 256, scripts/by_batch_forms.py);
+    // cattus_eval_config.tower_form forbids / forces it.
     bool winograd = false;
     // which Winograd kernel: the 4-frequencies x 2x2-blocks one (kernels_wino4.hip) wherever it covers the shape, else the
     // 16-frequencies one (kernels_wino.hip); same bits; diagnostic switch CATTUS_WINO_KERNEL=k16|k4
@@ -1171,8 +1173,8 @@ int create_impl(const void* weights, size_t nbytes, const cattus_eval_config* cf
     e->t64_layer_steps = !(t64_ls_env && atoi(t64_ls_env) == 0);
     e->split_wfrag = !(split_w_env && split_w_env[0] == '0');
     // the tower's form is part of the configuration (a leaf's bits must not depend on the batch it came in, so never per batch):
-    // AUTO = Winograd for max_batch >= 192 where the shape allows it; WINOGRAD on a shape it does not cover is refused below
-    e->winograd = cfg->tower_form == CATTUS_TOWER_WINOGRAD || (cfg->tower_form == CATTUS_TOWER_AUTO && cfg->max_batch >= 192);
+    // AUTO = Winograd for max_batch > 128 where the shape allows it; WINOGRAD on a shape it does not cover is refused below
+    e->winograd = cfg->tower_form == CATTUS_TOWER_WINOGRAD || (cfg->tower_form == CATTUS_TOWER_AUTO && cfg->max_batch > 128);
     e->resident_tower = !(tower64_env && tower64_env[0] == '0');
     e->t64s_fuse_heads = !(t64s_heads_env && t64s_heads_env[0] == '0');
     e->t64s_depth = t64s_d_env ? atoi(t64s_d_env) : 0;

@@ -54,8 +54,8 @@ typedef enum cattus_dtype {
 /* Form of the f16x2 conv tower on 8x8 boards with a multiple of 128 filters.  The two forms agree to < 2e-6 per logit but not
  * bit for bit, and a leaf's bits must not depend on the batch it came in: the form is fixed per evaluator, here. */
 typedef enum cattus_tower_form {
-    CATTUS_TOWER_AUTO = 0,     /* Winograd where the shape allows it and max_batch >= 192 (full batches), else direct */
-    CATTUS_TOWER_DIRECT = 1,   /* direct 3x3 (conv3x3_splitw_kernel): the faster form below ~192 leaves per batch */
+    CATTUS_TOWER_AUTO = 0,     /* Winograd where the shape allows it and max_batch > 128, else direct */
+    CATTUS_TOWER_DIRECT = 1,   /* direct 3x3 (conv3x3_splitw_kernel): the faster form up to 128 leaves per batch */
     CATTUS_TOWER_WINOGRAD = 2, /* Winograd F(2x2,3x3) whatever max_batch is; CATTUS_E_UNSUPPORTED where no such kernel exists */
 } cattus_tower_form;
 
@@ -176,7 +176,7 @@ int cattus_hip_planes_to_tensor_device(const uint64_t* d_planes, uint32_t n, uin
                                        uint32_t S, uint32_t batch, float* d_out, void* stream);
 
 /* Name of the kernel that runs this evaluator's tower (the dominant kernel of a forward pass): "conv3x3_splitw_kernel",
- * "conv3x3_wino_kernel" (f16x2 on 8x8 boards with max_batch >= 192), "tower64_split_kernel", "conv3x3_mfma_v2_kernel", ... */
+ * "conv3x3_wino_kernel" (f16x2 on 8x8 boards with max_batch > 128), "tower64_split_kernel", "conv3x3_mfma_v2_kernel", ... */
 const char* cattus_hip_tower_kernel(const cattus_eval* e);
 
 const char* cattus_hip_last_error(void);

@@ -9,7 +9,7 @@ Bars (DESIGN.md "Parity"):
     f32 runtime is (bounds F16X2_* below).
   * dtype bf16: bf16 operands / f32 accumulation; per-fixture bounds in BF16_MEASURED below (2x the measured error).
   * dtype f16: single-term f16 operands; per-fixture bounds in F16_MEASURED (2x the measured error, a tenth of bf16's).
-  * dtype f16x2 in Winograd form (evaluators of 8x8-board networks with max_batch >= 192): the f16x2 bars.
+  * dtype f16x2 in Winograd form (evaluators of 8x8-board networks with max_batch > 128): the f16x2 bars.
   * per-leaf results never depend on batch size, slot or neighbours (all dtypes, bit-exact).
 """
 
@@ -696,7 +696,7 @@ def test_device_pointer_entry_points_and_lanes_agree_with_host_entry_point():
 
 
 # ---- the split tower in Winograd F(2x2, 3x3) form: f16x2 evaluators of 8x8-board networks with a multiple of 64 filters (>= 128) and
-# max_batch >= 192 (or tower_form "winograd").  Two kernels, same bits: k4 = conv3x3_wino4_kernel (kernels_wino4.hip: 4 frequencies x
+# max_batch > 128 (or tower_form "winograd").  Two kernels, same bits: k4 = conv3x3_wino4_kernel (kernels_wino4.hip: 4 frequencies x
 # 2x2 blocks per wave, the default wherever it covers the shape), k16 = conv3x3_wino_kernel (kernels_wino.hip: 16 frequencies of one block) ----
 WINO_POLICY_ATOL_VS_F64, WINO_VALUE_ATOL_VS_F64 = 1.5e-6, 5e-7  # measured 5.1e-7 / 1.3e-7 (the direct split tower: 6.3e-7 / 2.1e-7)
 # k4 runs as ONE launch (tower_wino4_kernel: the layers chained by hand-off counters) while its grid fits the device, else per layer
@@ -709,7 +709,7 @@ def wino_eval(blob, batch_size, wk, **more):
 
 @pytest.mark.parametrize("wk", ["k4", "k16"])
 def test_winograd_tower_within_the_reference_tolerance_and_batch_independent(wk):
-    """chess 20x256 (the reference-made fixture): with max_batch >= 192 the f16x2 tower runs its 40 layers behind the stem in
+    """chess 20x256 (the reference-made fixture): with max_batch > 128 the f16x2 tower runs its 40 layers behind the stem in
     Winograd form -- 2.25x fewer MFMAs, operands transformed in f32 / float64 and split into f16 pairs, f32 activations between the
     layers.  Inside the reference's cross-runtime bar (training/tests/test_net_output.py:28-33), as close to the reference's float64
     run as the direct split tower, the same bits whatever the batch a leaf comes in, and selected by the configuration alone."""
