@@ -294,7 +294,8 @@ struct cattus_eval {
     // 16-frequencies one (kernels_wino.hip); same bits; diagnostic switch CATTUS_WINO_KERNEL=k16|k4
     bool wino_k4 = true;
     bool wino_k8 = false;  // CATTUS_WINO_KERNEL=k8: the eight-wave kernel (kernels_wino8.hip), per layer
-    // The Winograd tower as ONE launch (tower_wino4_kernel) while its grid fits the device, one workgroup per CU (diagnostic switch
+    // The Winograd tower as ONE launch (tower_wino4_kernel), one workgroup per CU, several tiles per workgroup and layer where a layer has
+    // more tiles than the device has CUs (diagnostic switch
     // CATTUS_WINO_PERSIST=0: per-layer launches; CATTUS_WINO_SPIN=<polls>: the budget of a hand-off wait).  persist_ok falls when
     // a launch reported a wait that gave up: the batch is run again on the per-layer launches, and so is every later one.
     bool wino_persist = true;
@@ -818,7 +819,7 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
                 HIP_TRY(hipMemsetAsync(L.tower_err.p, 0, 4, st));
                 int crc = chain_persistent_launch(e->device, st, [&] {
                     launch_tower_wino4(L.tower_layers.as<Wino4TowerLayer>(), L.tower_nlayers, L.tower_ready.as<unsigned>(), L.tower_err.as<unsigned>(),
-                                       e->conv_opts.saturated, nb, FP, e->persist_spin, st, s0, s1);
+                                       e->conv_opts.saturated, nb, FP, e->persist_spin, e->cus, st, s0, s1);
                 });
                 if (crc) return crc;
                 HIP_TRY(hipMemcpyAsync(L.h_tower_err.p, L.tower_err.p, 4, hipMemcpyDeviceToHost, st));

@@ -123,7 +123,7 @@ struct Wino4TowerLayer {
 };
 bool wino4_tower_fits(uint32_t bpad, uint32_t filters, uint32_t cus);
 void launch_tower_wino4(const Wino4TowerLayer* d_layers, uint32_t nlayers, unsigned* ready, unsigned* err, unsigned* sat, uint32_t bpad, uint32_t filters,
-                        uint32_t spin_budget, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
+                        uint32_t spin_budget, uint32_t cus, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // Diagnostic: one launch of nothing but back-to-back MFMAs of the tower's kind (F16S: f16, BF16, F32: 32x32x2 f32), four
 // waves on each of `cus` workgroups, iters x 4 MFMAs per wave; `out` holds cus * 256 floats.  Returns the launch's FLOPs.

@@ -79,7 +79,9 @@ struct W4Sync {
 template <int RES, bool PERSIST>
 __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Float16* __restrict__ wu, const float* __restrict__ bias,
                                          const float* res, float* out, unsigned* __restrict__ sat, int cin, int cout, char* smem,
-                                         const W4Sync& sync) {
+                                         const W4Sync& sync, int wg, int nblk) {
+    // wg of nblk: the workgroup's index in the layer's grid -- blockIdx.x of the per-layer launch; in the tower kernel a workgroup takes
+    // several of them per layer when the layer has more tiles than the device has CUs
     typedef _Float16 T;
     typedef Mfma<T>::frag frag;
     constexpr bool has_res = RES == 1;
@@ -96,9 +98,9 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave = the frequency row it owns
     const int lane = tid & 63;
 
-    const int nblk = gridDim.x, ncg = cout >> 6;
-    int logical = blockIdx.x;
-    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);  // one XCD: all cout groups of a range of boards
+    const int ncg = cout >> 6;
+    int logical = wg;
+    if ((nblk & 7) == 0) logical = (wg & 7) * (nblk >> 3) + (wg >> 3);  // one XCD: all cout groups of a range of boards
     const int cout0 = (logical % ncg) * 64;   // the workgroup's 64 output channels
     const int row0 = (logical / ncg) * 256;   // first tower row of its four boards
 
@@ -540,7 +542,7 @@ __global__ void __launch_bounds__(256, 1)
                          const float* res, float* out, unsigned* __restrict__ sat, int cin, int cout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const W4Sync none{};
-    w4_layer<HAS_RES ? 1 : 0, false>(in, wu, bias, res, out, sat, cin, cout, smem, none);
+    w4_layer<HAS_RES ? 1 : 0, false>(in, wu, bias, res, out, sat, cin, cout, smem, none, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- the whole Winograd tower in ONE launch (round 5; the review's "persistent tower") ----
@@ -554,15 +556,22 @@ __global__ void __launch_bounds__(256, 1)
 // the batch again on the per-layer launches.
 __global__ void __launch_bounds__(256, 1)
     tower_wino4_kernel(const Wino4TowerLayer* __restrict__ layers, int nlayers, unsigned* ready, unsigned* err, unsigned* __restrict__ sat, int filters,
-                       unsigned spin_budget) {
+                       unsigned spin_budget, int tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nblk = gridDim.x, ncg = filters >> 6, ngroups = nblk / ncg;
-    int logical = blockIdx.x;
-    if ((nblk & 7) == 0) logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);  // the map of w4_layer
-    const int group = logical / ncg;
+    // `tiles` = workgroups of a layer's grid (boards / 4 x cout groups).  More of them than the device has CUs (config 5's shape: 768):
+    // the launch is as many workgroups as fit, and a workgroup takes tile blockIdx.x + r gridDim.x in round r of every layer.  The
+    // hand-off never waits forward: a tile of layer n depends on tiles of layer n - 1 only, every workgroup walks layers and rounds in
+    // the same order, so whoever is waited for is running or done.  (tiles and gridDim.x multiples of 8: a tile's XCD is blockIdx.x & 7
+    // in every round, and the cout groups of a board group sit on one XCD as in the per-layer launches.)
+    const int ncg = filters >> 6, ngroups = tiles / ncg;
+    auto group_of = [&](int wg) {
+        int logical = wg;
+        if ((tiles & 7) == 0) logical = (wg & 7) * (tiles >> 3) + (wg >> 3);  // the map of w4_layer
+        return logical / ncg;
+    };
     // a residual block = two layers: the first without skip rows, the second with (two instantiations of the layer: decided at run time,
     // the skip registers' undefined values on the path without them cost 32 spilled registers)
-    auto sync_of = [&](int layer) {
+    auto sync_of = [&](int layer, int group) {
         W4Sync sync;
         sync.wait_word = layer > 0 ? ready + (size_t)(layer - 1) * ngroups + group : nullptr;
         sync.done_word = ready + (size_t)layer * ngroups + group;
@@ -571,9 +580,11 @@ __global__ void __launch_bounds__(256, 1)
     };
     for (int layer = 0; layer + 1 < nlayers; layer += 2) {
         const Wino4TowerLayer A = layers[layer];
-        w4_layer<0, true>(A.in, reinterpret_cast<const _Float16*>(A.wu), A.bias, nullptr, A.out, sat, filters, filters, smem, sync_of(layer));
+        for (int wg = blockIdx.x; wg < tiles; wg += gridDim.x)
+            w4_layer<0, true>(A.in, reinterpret_cast<const _Float16*>(A.wu), A.bias, nullptr, A.out, sat, filters, filters, smem, sync_of(layer, group_of(wg)), wg, tiles);
         const Wino4TowerLayer B = layers[layer + 1];
-        w4_layer<1, true>(B.in, reinterpret_cast<const _Float16*>(B.wu), B.bias, B.res, B.out, sat, filters, filters, smem, sync_of(layer + 1));
+        for (int wg = blockIdx.x; wg < tiles; wg += gridDim.x)
+            w4_layer<1, true>(B.in, reinterpret_cast<const _Float16*>(B.wu), B.bias, B.res, B.out, sat, filters, filters, smem, sync_of(layer + 1, group_of(wg)), wg, tiles);
     }
 }
 
@@ -593,15 +604,20 @@ void launch_conv3x3_wino4(const float* in, const void* wu, const float* bias, co
                               sat, (int)cin, (int)cout);
 }
 
+// The launch's grid for `tiles` tiles on `cus` CUs: all of them when they fit, else the largest multiple of 8 that does (one workgroup
+// per CU, all resident: what the hand-off counters rely on), each workgroup taking several tiles per layer.
+static uint32_t tower_grid(uint32_t tiles, uint32_t cus) { return tiles <= cus ? tiles : cus & ~7u; }
+
 bool wino4_tower_fits(uint32_t bpad, uint32_t filters, uint32_t cus) {
-    return (bpad / 4) * (filters / 64) <= cus;  // one workgroup per CU, all resident: what the hand-off counters rely on
+    const uint32_t tiles = (bpad / 4) * (filters / 64);
+    return tiles <= cus || (cus >= 8 && tiles % 8 == 0);  // (tiles % 8: the block-index map keeps a tile on one XCD through the rounds)
 }
 
 void launch_tower_wino4(const Wino4TowerLayer* d_layers, uint32_t nlayers, unsigned* ready, unsigned* err, unsigned* sat, uint32_t bpad, uint32_t filters,
-                        uint32_t spin_budget, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const dim3 grid((bpad / 4) * (filters / 64));
-    hipExtLaunchKernelGGL(tower_wino4_kernel, grid, dim3(256), W4_LDS_TOTAL, st, ev_start, ev_stop, 0, d_layers, (int)nlayers, ready, err, sat, (int)filters,
-                          spin_budget);
+                        uint32_t spin_budget, uint32_t cus, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const uint32_t tiles = (bpad / 4) * (filters / 64);
+    hipExtLaunchKernelGGL(tower_wino4_kernel, dim3(tower_grid(tiles, cus)), dim3(256), W4_LDS_TOTAL, st, ev_start, ev_stop, 0, d_layers, (int)nlayers, ready, err,
+                          sat, (int)filters, spin_budget, (int)tiles);
 }
 
 #ifdef CATTUS_STAMPS

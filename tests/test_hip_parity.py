@@ -779,12 +779,14 @@ def test_winograd_kernels_agree_bit_for_bit(shape):
         assert np.abs(a[0] - b[0]).max() < 2e-6 and np.abs(a[1] - b[1]).max() < 1e-6
 
 
-@pytest.mark.parametrize("shape", [(3, 128, 256), (3, 128, 512), (20, 256, 256), (2, 384, 168), (2, 192, 77)])
+@pytest.mark.parametrize("shape", [(3, 128, 256), (3, 128, 512), (20, 256, 256), (2, 384, 168), (2, 192, 77), (2, 384, 512), (3, 256, 384)])
 def test_one_launch_winograd_tower_equals_the_per_layer_launches(shape):
     """tower_wino4_kernel -- every layer behind the stem in one launch, a workgroup keeping its (4 boards x 64 couts) tile through all
     of them, the layers chained by a counter per (layer, board group) -- against the same layers as launches of their own
     (CATTUS_WINO_PERSIST=0): the same bits, on a full grid (one workgroup per CU), on partial batches of the same evaluator, on both
-    lanes back to back, and again after many passes (stale lines in a CU's L1 or a missed hand-off would show as wrong rows)."""
+    lanes back to back, and again after many passes (stale lines in a CU's L1 or a missed hand-off would show as wrong rows).  The last
+    two shapes have more tiles than the device has CUs (768: three per workgroup and layer -- config 5's; 384: the second round half
+    empty): a workgroup walks its tiles layer by layer, board groups straddle the rounds."""
     blocks, filters, n = shape
     d = NetDesc(**CHESS, blocks=blocks, filters=filters, vhc=8, phc=8)
     blob = seeded_blob(d, 31)
@@ -793,7 +795,7 @@ def test_one_launch_winograd_tower_equals_the_per_layer_launches(shape):
         assert ev.tower_kernel() == "conv3x3_wino4_kernel"
         want = ev.eval(planes)
     with wino_eval(blob, n, "k4") as ev:
-        assert ev.tower_kernel() == "tower_wino4_kernel"  # (n / 4 board groups) x (filters / 64 cout groups) <= 256 CUs
+        assert ev.tower_kernel() == "tower_wino4_kernel"  # (n / 4 board groups) x (filters / 64 cout groups) tiles, on 256 CUs
         for rep in range(6):
             got = ev.eval(planes)  # alternates between the lanes' buffers
             assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), rep
@@ -874,7 +876,7 @@ def test_winograd_tower_tracks_the_f32_tower_at_full_size(net, n, bound):
     with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f32") as ev:
         want_p, want_v = ev.eval(planes)
     with HipEvaluator(blob, batch_size=n, plane_words=1, dtype="f16x2", switches={}) as ev:
-        assert ev.tower_kernel() == ("tower_wino4_kernel" if net == "20x256" else "conv3x3_wino4_kernel")  # what bench.py's headline is timed on
+        assert ev.tower_kernel() == "tower_wino4_kernel"  # what bench.py's headline is timed on (40x384 at 512 leaves: 768 tiles, three per workgroup and layer)
         got_p, got_v = ev.eval(planes)
     assert np.isfinite(got_p).all() and np.isfinite(got_v).all()
     assert np.abs(got_p - want_p).max() <= bound[0] and np.abs(got_v - want_v).max() <= bound[1]
