@@ -245,7 +245,7 @@ struct Lane {
     PinnedBuf h_planes, h_policy, h_value;
     // the Winograd tower in one launch (tower_wino4_kernel): this lane's layer table, hand-off counters and error word, and the
     // page-locked word the error word is copied to behind every such launch
-    DevBuf tower_layers, tower_ready, tower_err;
+    DevBuf tower_layers, tower_ready;  // tower_ready: [error word, pad to 64 B | a counter per (layer, board group)] -- one memset per batch
     PinnedBuf h_tower_err;
     uint32_t tower_nlayers = 0;
     std::mutex mu;  // held while a batch uses the lane
@@ -717,8 +717,7 @@ int build(cattus_eval* e, const float* p) {
             }
             L.tower_nlayers = (uint32_t)tl.size();
             if ((rc = L.tower_layers.upload(tl.data(), tl.size() * sizeof(Wino4TowerLayer)))) return rc;
-            if ((rc = L.tower_ready.alloc((size_t)tl.size() * (bp_ / 4) * 4))) return rc;
-            if ((rc = L.tower_err.alloc(4))) return rc;
+            if ((rc = L.tower_ready.alloc(64 + (size_t)tl.size() * (bp_ / 4) * 4))) return rc;
             if ((rc = L.h_tower_err.alloc(4))) return rc;
             *L.h_tower_err.as<unsigned>() = 0;
         }
@@ -815,14 +814,14 @@ int enqueue_forward(cattus_eval* e, Lane& L, const uint64_t* d_planes, uint32_t 
                 // every layer behind the stem in ONE launch: counters and error word zeroed ahead of it on the same stream, the error word
                 // copied to page-locked memory behind it (eval_host reads it when the batch is back; the device entry points at their next call)
                 hipEvent_t s0 = ev(false), s1 = ev(true);
-                HIP_TRY(hipMemsetAsync(L.tower_ready.p, 0, (size_t)L.tower_nlayers * (nb / 4) * 4, st));
-                HIP_TRY(hipMemsetAsync(L.tower_err.p, 0, 4, st));
+                unsigned* const tower_err = L.tower_ready.as<unsigned>();
+                HIP_TRY(hipMemsetAsync(L.tower_ready.p, 0, 64 + (size_t)L.tower_nlayers * (nb / 4) * 4, st));
                 int crc = chain_persistent_launch(e->device, st, [&] {
-                    launch_tower_wino4(L.tower_layers.as<Wino4TowerLayer>(), L.tower_nlayers, L.tower_ready.as<unsigned>(), L.tower_err.as<unsigned>(),
+                    launch_tower_wino4(L.tower_layers.as<Wino4TowerLayer>(), L.tower_nlayers, tower_err + 16, tower_err,
                                        e->conv_opts.saturated, nb, FP, e->persist_spin, e->cus, st, s0, s1);
                 });
                 if (crc) return crc;
-                HIP_TRY(hipMemcpyAsync(L.h_tower_err.p, L.tower_err.p, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(L.h_tower_err.p, tower_err, 4, hipMemcpyDeviceToHost, st));
             } else
             for (uint32_t i = 0; i < d.blocks; i++) {
                 conv(*e->c1[i], a, nullptr, t, 0);
