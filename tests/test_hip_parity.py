@@ -748,6 +748,25 @@ def test_winograd_tower_form_is_refused_where_no_kernel_covers_the_shape():
     assert ei.value.status == -2  # CATTUS_E_UNSUPPORTED
 
 
+def test_auto_form_follows_max_batch_and_never_the_batch():
+    """cattus_eval_config.tower_form = AUTO: the direct kernels up to max_batch 128, the Winograd tower above (scripts/by_batch_forms.py:
+    0.97 | 0.90 ms per step at 128 leaves, 1.45 | 0.93 at 160) -- fixed when the evaluator is created: a 3-leaf batch of a 256-leaf
+    evaluator runs the kernel its full batches run, and its leaves get the bits they get in a full batch."""
+    d = NetDesc(**CHESS, blocks=2, filters=128, vhc=8, phc=8)
+    blob = seeded_blob(d, 12)
+    planes = synth.random_chess_planes(160, 12)
+    with HipEvaluator(blob, batch_size=128, plane_words=1, dtype="f16x2", switches={}) as ev:
+        assert ev.tower_kernel() == "conv3x3_splitw_kernel"
+    with HipEvaluator(blob, batch_size=129, plane_words=1, dtype="f16x2", switches={}) as ev:
+        assert ev.tower_kernel() == "tower_wino4_kernel"
+    with HipEvaluator(blob, batch_size=160, plane_words=1, dtype="f16x2", switches={}) as ev:
+        assert ev.tower_kernel() == "tower_wino4_kernel"
+        full = ev.eval(planes)
+        few = ev.eval(planes[:3])
+        assert ev.tower_kernel() == "tower_wino4_kernel"
+    assert (few[0] == full[0][:3]).all() and (few[1] == full[1][:3]).all()
+
+
 @pytest.mark.parametrize("shape", [(3, 128, 256), (2, 192, 200), (2, 256, 24), (1, 384, 512)])
 def test_winograd_kernels_agree_bit_for_bit(shape):
     """conv3x3_wino4_kernel and conv3x3_wino8_kernel against conv3x3_wino_kernel: per accumulator the same MFMA sequence, V and Y combined in the same order --
