@@ -176,7 +176,8 @@ int cattus_hip_planes_to_tensor_device(const uint64_t* d_planes, uint32_t n, uin
                                        uint32_t S, uint32_t batch, float* d_out, void* stream);
 
 /* Name of the kernel that runs this evaluator's tower (the dominant kernel of a forward pass): "conv3x3_splitw_kernel",
- * "conv3x3_wino_kernel" (f16x2 on 8x8 boards with max_batch > 128), "tower64_split_kernel", "conv3x3_mfma_v2_kernel", ... */
+ * "tower_wino4_kernel" (f16x2 on 8x8 boards with max_batch > 128: the Winograd tower, every layer behind the stem in one launch),
+ * "tower64_split_kernel", "conv3x3_mfma_v2_kernel", ... */
 const char* cattus_hip_tower_kernel(const cattus_eval* e);
 
 const char* cattus_hip_last_error(void);
