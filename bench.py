@@ -734,7 +734,12 @@ def main():
             "kernel": r["kernel"],
             "bound": bound,
             "bound_note": "l2_delivery: the loop is a stream of L2-resident operands into the CUs (`delivery`), the matrix pipe waits for it; "
-                          "`frac` stays the MFMA fraction on algorithmic FLOPs for comparison across kernels" if bound != "mfma" else None,
+                          "`frac` stays the MFMA fraction on algorithmic FLOPs for comparison across kernels" if bound != "mfma" else
+                          # the contract's roof for a tower is the matrix pipe; what keeps THIS kernel from it is neither roof on the line
+                          ("mfma is the roof priced here; what the kernel sits under is the issue rate of its one wave per SIMD -- per 48 MFMAs "
+                           "(1,536 pipe cycles) the wave issues ~360 other instructions whose costs add up to ~2,300 cycles "
+                           "(profiles/r05_gap_cost_probe.txt, DESIGN.md section 3 K1w4) -- and, with two waves per SIMD, socket power (K1w8)"
+                           if r["kernel"] in ("tower_wino4_kernel", "conv3x3_wino4_kernel") else None),
             "delivery": deliv,
             "achieved": achieved,
             "peak": peak,
