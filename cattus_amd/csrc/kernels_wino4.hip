@@ -37,15 +37,19 @@
 
 namespace cattus {
 
-constexpr int W4_RP = 8 * SP + 64;            // pitch of a board row in a chunk image: 8 pixels of 144 B + 64 B (K1w's)
-constexpr int W4_IMG = 16 * W4_RP;            // one tile block's image: 2 boards x 8 rows = 19,456 B
-constexpr int W4_ZAREA = 4608;                // behind each image: its zero area (patch pixels off the board)
-constexpr int W4_IMGZ = W4_IMG + W4_ZAREA;    // 24,064 B
-constexpr int W4_DBUF = 2 * W4_IMGZ;          // a chunk buffer: both tile blocks = 48,128 B
-constexpr int W4_LDS_LOOP = 2 * W4_DBUF;      // 96,256 B
+// A chunk in LDS is held ROW-COMBINED: for every frequency row q the image T_q[board][tile row ty][column x] = d[2 ty - 1 + ra_q][x] +-
+// d[2 ty - 1 + rb_q][x] (B^T row q: what every tile of that tile row needs of its column x), made ONCE per chunk by the threads that
+// fetched the rows -- instead of once per wave and tile column by the transform (neighbouring tiles share two of their four columns).
+constexpr int W4_TROW = 8 * SP;               // pitch of an image row (a board's tile row: 8 pixels of 144 B) = 72 sixteen-byte slots = 8 mod 16
+constexpr int W4_IMG = 9472;                  // one (frequency row, tile block) image: 2 boards x 4 tile rows x 1,152 B + the second board's 16 B, to 256
+constexpr int W4_ZAREA = 512;                 // behind each image: its zero area (patch columns off the board)
+constexpr int W4_IMGZ = W4_IMG + W4_ZAREA;    // 9,984 B
+constexpr int W4_DBUF = 8 * W4_IMGZ;          // a chunk buffer: 4 frequency rows x 2 tile blocks = 79,872 B
+constexpr int W4_LDS_LOOP = 2 * W4_DBUF;      // 159,744 B of the CU's 163,840
 constexpr int W4_LDS_Z = 4 * 2 * 64 * 256;    // the epilogue's exchange: [wave][c'][tile][64 couts f32] = 131,072 B
 constexpr int W4_LDS_TOTAL = W4_LDS_Z > W4_LDS_LOOP ? W4_LDS_Z : W4_LDS_LOOP;
 static_assert(W4_IMG % 256 == 0 && W4_IMGZ % 256 == 0 && W4_DBUF % 256 == 0, "the zero area keeps a read's banks only if everything is 256-B aligned");
+static_assert(W4_IMG >= 8 * W4_TROW + 16 && W4_ZAREA >= 256 + 128 && W4_LDS_LOOP <= 160 * 1024, "image / zero area / LDS sizes");
 
 typedef __attribute__((ext_vector_type(2))) _Float16 w4_f16x2;
 
@@ -141,11 +145,15 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     // i of thread t = pixel row 32 i + (t >> 3), piece t & 7 -- a wave instruction reads eight whole 128-byte rows.  Image layout per
     // tile block as in K1w: pixel pitch 144 B, board rows of 8 pixels + 64 B, the second board one 16-B piece to the right, zero area behind.
     const char* abase0 = reinterpret_cast<const char*>(in) + (size_t)row0 * row_bytes;
-    const uint32_t aoff = (uint32_t)(tid >> 3) * row_bytes + (tid & 7) * 16;
-    const uint32_t wdst = (uint32_t)(q * W4_RP + ((tid >> 3) & 7) * SP + (tid & 7) * 16);  // pixel row 32 i + (t >> 3) = board row 4 i + q, column (t >> 3) & 7
+    // wave q fetches board q of the workgroup's four: thread = (column x = (t >> 3) & 7, 16-byte piece t & 7), load i = board row i -- a wave
+    // instruction reads the eight whole 128-byte rows of one board row; a thread ends up with all eight rows of its column
+    const uint32_t aoff = (uint32_t)(q * 64 + ((tid >> 3) & 7)) * row_bytes + (tid & 7) * 16;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;  // the workgroup's LDS base (0 here: an add the compiler cannot fold)
+    // where this thread's T values go: tile block q >> 1, board q & 1 of it (four image rows down, 16 B to the right), column, piece
+    const uint32_t wdst = lds0 + (uint32_t)((q >> 1) * W4_IMGZ + (q & 1) * (4 * W4_TROW + 16) + ((tid >> 3) & 7) * SP + (tid & 7) * 16);
     constexpr int W4_NP = 8;  // loads per thread and chunk: they count in vmcnt like the ring's
     auto load_piece = [&](u32x4& reg, int ch, int i) __attribute__((always_inline)) {
-        const char* src = abase0 + (size_t)ch * 128 + (size_t)i * 32 * row_bytes;
+        const char* src = abase0 + (size_t)ch * 128 + (size_t)i * 8 * row_bytes;
         u32x4 r;
         if (PERSIST) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(r) : "v"(aoff), "s"(src) : "memory");
         else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(aoff), "s"(src) : "memory");
@@ -155,12 +163,27 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
 #pragma unroll
         for (int i = 0; i < W4_NP; i++) load_piece(regs[i], ch, i);
     };
-    auto store_piece = [&](const u32x4(&regs)[W4_NP], uint32_t dbuf_plus_wdst, int i) __attribute__((always_inline)) {
-        // board row 4 i + q of the workgroup's 32: tile block i >> 2, board (i >> 1) & 1 of it, row 4 (i & 1) + q of that board
-        const int imm = (i >> 2) * W4_IMGZ + ((i & 3) * 4) * W4_RP + ((i >> 1) & 1) * 16;
-        *reinterpret_cast<u32x4*>(smem + dbuf_plus_wdst + imm) = regs[i];
+    // T unit u = (frequency row fq = u >> 2, tile row ty = u & 3) of this thread's column: t = fma(d[rb], sg, d[ra]) on rows 2 ty - 1 + (ra, rb)
+    // -- K1w's instruction on K1w's operands (B^T row fq: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3); a row off the board is +0.0:
+    // above the board (fq 0, ty 0) the addend is the constant, below it (fq 3, ty 3) fma(+0, -1, d) is d itself
+    auto t_unit = [&](const u32x4(&regs)[W4_NP], uint32_t target, int u) __attribute__((always_inline)) {
+        const int fq = u >> 2, ty = u & 3;
+        const int ra = fq == 0 ? 0 : fq == 2 ? 2 : 1, rb = fq == 3 ? 3 : fq == 2 ? 1 : 2;
+        const int ya = 2 * ty - 1 + ra, yb = 2 * ty - 1 + rb;
+        u32x4 t;
+        if (yb > 7) t = regs[ya];
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (ya < 0) asm("v_fma_f32 %0, %1, -1.0, 0" : "=v"(t[e]) : "v"(regs[yb][e]));
+                else if (fq == 1) asm("v_fma_f32 %0, %1, 1.0, %2" : "=v"(t[e]) : "v"(regs[yb][e]), "v"(regs[ya][e]));
+                else asm("v_fma_f32 %0, %1, -1.0, %2" : "=v"(t[e]) : "v"(regs[yb][e]), "v"(regs[ya][e]));
+            }
+        }
+        typedef __attribute__((address_space(3))) u32x4 w4_lu32x4;
+        *(w4_lu32x4*)(uintptr_t)(target + (uint32_t)(fq * 2 * W4_IMGZ + ty * W4_TROW)) = t;
     };
-    for (int i = tid; i < 4 * (W4_ZAREA / 16); i += 256)  // the four zero areas
+    for (int i = tid; i < 16 * (W4_ZAREA / 16); i += 256)  // the sixteen zero areas
         reinterpret_cast<f32x4*>(smem + (i / (W4_ZAREA / 16)) * W4_IMGZ + W4_IMG)[i % (W4_ZAREA / 16)] = f32x4{0.f, 0.f, 0.f, 0.f};
     // The ring's l = 0, 1 first -- the weights do not depend on anybody --, then (PERSIST) the wait for the board group's producers of the
     // previous layer, then chunk 0, chunk 1 and the ring's l = 2: the ORDER of the steady state (per k-step: l = 0 in stage 3, l = 1 in
@@ -198,35 +221,27 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     load_ustage(ring[2], wks, 2);
 
     // ---- the transform's geometry: lane = (tile n of the tile block, k-half hh): board n >> 4, tile row (n >> 2) & 3, column n & 3 ----
-    // Wave q combines the patch rows (ra, rb) of its tile: q = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 (B^T row q), as
-    // t = fma(d[rb], sg, d[ra]) with sg = +-1 (the product is exact: the bits of the sum / difference).  The patch pixel (r, c) is at
-    // image + tbase + r W4_RP + c SP; rows 0 / 3 and columns 0 / 3 can lie off the board: those reads go to the image's zero area at
-    // the read's own address mod 256 (the same banks) + the same offset -- folded into six base registers (row a / b x column
-    // class 0 / 1-2 / 3) that already point into the current chunk buffer.
+    // Wave q reads ITS image: the four columns 2 tx - 1 .. 2 tx + 2 of image row (board, ty), at image + tbase + c SP.  Columns 0 / 3 can
+    // lie off the board: those reads go to the image's zero area at the read's own address mod 256 (the same banks) -- folded into three
+    // base registers (column class 0 / 1-2 / 3) that already point into the current chunk buffer.  (Pixel pitch 9 slots of 16 B, row pitch
+    // 72 = 8 mod 16, the second board one slot to the right: the 16 lanes of every ds_read_b128 lane group on 16 different slots.)
     const int n = lane & 31, hh = lane >> 5;
     const int b2 = n >> 4, ty = (n >> 2) & 3, tx = n & 3;
-    const int ra = q == 0 ? 0 : q == 2 ? 2 : 1, rb = q == 3 ? 3 : q == 2 ? 1 : 2;
-    const float sg = q == 1 ? 1.0f : -1.0f;  // wave-uniform: an SGPR operand of the asm fma below
-    uint32_t cur[2][3];
+    uint32_t cur[3];
     {
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;  // the workgroup's LDS base (0 here: an add the compiler cannot fold)
-        const int tbase = ((b2 * 8 + 2 * ty - 1) * W4_RP) + (2 * tx - 1) * SP + b2 * 16 + hh * 32;
+        const int tbase = (b2 * 4 + ty) * W4_TROW + (2 * tx - 1) * SP + b2 * 16 + hh * 32;
         const int tdelta = tbase - W4_IMG;
-        const int mra = (ra == 0 && ty == 0) ? 255 : -1, mrb = (rb == 3 && ty == 3) ? 255 : -1;
         const int mc0 = tx != 0 ? -1 : 255, mc3 = tx != 3 ? -1 : 255;
-#pragma unroll
-        for (int X = 0; X < 2; X++) {
-            const int mr = X ? mrb : mra, rr = X ? rb : ra;
-            cur[X][0] = lds0 + (uint32_t)(W4_IMG + (tdelta & mr & mc0) + rr * W4_RP);
-            cur[X][1] = lds0 + (uint32_t)(W4_IMG + (tdelta & mr) + rr * W4_RP + SP);
-            cur[X][2] = lds0 + (uint32_t)(W4_IMG + (tdelta & mr & mc3) + rr * W4_RP + 3 * SP);
-        }
+        const uint32_t img = lds0 + (uint32_t)(q * 2 * W4_IMGZ + W4_IMG);
+        cur[0] = img + (uint32_t)(tdelta & mc0);
+        cur[1] = img + (uint32_t)(tdelta + SP);
+        cur[2] = img + (uint32_t)(((tdelta + 3 * SP) & mc3));
     }
     int bufstep = W4_DBUF;  // cur[] += bufstep at every chunk change, bufstep = -bufstep
 
     // V registers (MFMA B operands): [tb][l] for l = 0, 1; two sets [k-step parity][tb][l - 2] for l = 2, 3
     u32x4 vh01[2][2], vl01[2][2], vh23[2][2][2], vl23[2][2][2];
-    f32x4 pa[4], pb[4], tt[4];  // the patch rows of a 4-channel group, and their combination (one f32x4 per patch column)
+    f32x4 tbuf[2][4];           // a 4-channel group's row-combined patch, one f32x4 per patch column: [group parity], read a group ahead
     f32x4 xx;                   // a frequency's four values between the two halves of its slice
     float vmax = 0.0f;
 
@@ -236,13 +251,28 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
     auto freq_slot = [&](int sp, int tbv, int g, int l, int half) __attribute__((always_inline)) {
         // sp = parity of the k-step the phase makes V for (which l = 2,3 set), g = 4-channel group, l = frequency column
         if (half == 0) {
-            xx = l == 0 ? tt[0] - tt[2] : l == 1 ? tt[1] + tt[2] : l == 2 ? tt[2] - tt[1] : tt[1] - tt[3];
+            // (one asm statement, conversions included: the compiler packs the C form of the column combination into v_pk_add_f32 -- 14
+            // cycles of issue beside MFMAs for what two 4-cycle instructions do -- and puts an s_nop behind every asm statement whose
+            // registers its own next instruction reads)
+            const f32x4(&tt)[4] = tbuf[g];
+            const int ca = l == 0 ? 0 : l == 2 ? 2 : 1, cb = l == 0 ? 2 : l == 1 ? 2 : l == 2 ? 1 : 3;
             // |x| <= 65504: x is a signed sum of four activations, capped where they were written at WINO_ACT_MAX = 65504 / 4
-            const w4_f16x2 h0 = __builtin_convertvector(__builtin_shufflevector(xx, xx, 0, 1), w4_f16x2);
-            const w4_f16x2 h1 = __builtin_convertvector(__builtin_shufflevector(xx, xx, 2, 3), w4_f16x2);
+            float x0, x1, x2, x3;
+            uint32_t h0, h1;
+            if (l == 1)
+                asm("v_add_f32 %2, %6, %10\n\tv_add_f32 %3, %7, %11\n\tv_add_f32 %4, %8, %12\n\tv_add_f32 %5, %9, %13\n\t"
+                    "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+                    : "=&v"(h0), "=&v"(h1), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                    : "v"(tt[ca][0]), "v"(tt[ca][1]), "v"(tt[ca][2]), "v"(tt[ca][3]), "v"(tt[cb][0]), "v"(tt[cb][1]), "v"(tt[cb][2]), "v"(tt[cb][3]));
+            else
+                asm("v_sub_f32 %2, %6, %10\n\tv_sub_f32 %3, %7, %11\n\tv_sub_f32 %4, %8, %12\n\tv_sub_f32 %5, %9, %13\n\t"
+                    "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+                    : "=&v"(h0), "=&v"(h1), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                    : "v"(tt[ca][0]), "v"(tt[ca][1]), "v"(tt[ca][2]), "v"(tt[ca][3]), "v"(tt[cb][0]), "v"(tt[cb][1]), "v"(tt[cb][2]), "v"(tt[cb][3]));
+            xx = f32x4{x0, x1, x2, x3};
             u32x4& dst = l < 2 ? vh01[tbv][l] : vh23[sp][tbv][l - 2];
-            dst[2 * g] = __builtin_bit_cast(uint32_t, h0);
-            dst[2 * g + 1] = __builtin_bit_cast(uint32_t, h1);
+            dst[2 * g] = h0;
+            dst[2 * g + 1] = h1;
         } else {
             // lo = f16(x - hi): the difference is exact in f32 (v_fma_mix_f32 takes hi as the f16 it is: no conversion back), one
             // v_cvt_pk_f16_f32 rounds two of them.  The same bits as v_fma_mixlo/hi_f16 (K1w), which round the same f32 difference -- but
@@ -263,39 +293,28 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
             dst[2 * g] = lo0, dst[2 * g + 1] = lo1;
         }
     };
-    auto read_row = [&](f32x4(&dstv)[4], int X, int tbv, int kp, int g) __attribute__((always_inline)) {
+    auto read_group = [&](f32x4(&dstv)[4], int tbv, int kp, int g) __attribute__((always_inline)) {
         const int imm = tbv * W4_IMGZ + kp * 64 + g * 16;
         // (cur[] are LDS addresses, the workgroup's base included: as `smem + offset` every read pair paid a v_add of the base)
         typedef const __attribute__((address_space(3))) f32x4 w4_lf32x4;
-        dstv[0] = *(w4_lf32x4*)(uintptr_t)(cur[X][0] + imm);
-        dstv[1] = *(w4_lf32x4*)(uintptr_t)(cur[X][1] + imm);
-        dstv[2] = *(w4_lf32x4*)(uintptr_t)(cur[X][1] + imm + SP);
-        dstv[3] = *(w4_lf32x4*)(uintptr_t)(cur[X][2] + imm);
+        dstv[0] = *(w4_lf32x4*)(uintptr_t)(cur[0] + imm);
+        dstv[1] = *(w4_lf32x4*)(uintptr_t)(cur[1] + imm);
+        dstv[2] = *(w4_lf32x4*)(uintptr_t)(cur[1] + imm + SP);
+        dstv[3] = *(w4_lf32x4*)(uintptr_t)(cur[2] + imm);
     };
-    // slot j of phase (sp = parity of the target k-step, tbv).  A group's twelve slots: 0, 1 combine its patch rows (read ten slots
+    // slot j of phase (sp = parity of the target k-step, tbv).  A group's twelve slots: 0 takes over its four columns (read ten slots
     // earlier: an LDS read that four waves issue at once takes ~200 cycles to come back, and a wave that waits for it stops issuing
-    // MFMAs); 2, 3 read the rows of the NEXT group (the next phase's group 0 behind group 1); 4..11 the four frequencies
+    // MFMAs); 2 reads the columns of the NEXT group (the next phase's group 0 behind group 1); 4..11 the four frequencies
     auto slot = [&](int sp, int tbv, int j) __attribute__((always_inline)) {
         const int g = j / 12, jj = j % 12;
-        if (jj < 2) {
-            // (the group's eight reads were issued ten slots ago: all of them are operands of the slot's first instruction and waited for
-            // once -- the compiler would count them down read by read, four s_waitcnt per group, an issue slot each)
-#pragma unroll
-            for (int c = 2 * jj; c < 2 * jj + 2; c++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (jj == 0 && c == 0 && e == 0)
-                        asm("v_fma_f32 %0, %1, %2, %3"
-                            : "=v"(tt[c][e])
-                            : "v"(pb[c][e]), "s"(sg), "v"(pa[c][e]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]));
-                    else asm("v_fma_f32 %0, %1, %2, %3" : "=v"(tt[c][e]) : "v"(pb[c][e]), "s"(sg), "v"(pa[c][e]));
-                }
-        } else if (jj < 4) {
+        if (jj == 0) {
+            // (all four reads waited for once, as operands of one statement -- the compiler would count them down read by read)
+            asm volatile("" : "+v"(tbuf[g][0]), "+v"(tbuf[g][1]), "+v"(tbuf[g][2]), "+v"(tbuf[g][3]));
+        } else if (jj == 2) {
             // behind (s, tb0) comes (s, tb1), behind (s, tb1) comes (s + 1, tb0)
             const int nsp = g == 0 || tbv == 0 ? sp : sp ^ 1, ntb = g == 0 ? tbv : tbv ^ 1, ng = g ^ 1;
-            if (jj == 2) read_row(pa, 0, ntb, nsp, ng);
-            else read_row(pb, 1, ntb, nsp, ng);
-        } else {
+            read_group(tbuf[ng], ntb, nsp, ng);
+        } else if (jj >= 4) {
             freq_slot(sp, tbv, g, (jj - 4) >> 1, (jj - 4) & 1);
         }
     };
@@ -310,16 +329,16 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[l][t2][c][e] = 0.0f;
 
-    // ---- prologue: chunk 0 has landed (everything but chunk 1's 8 loads and the ring's last 4) and goes to buffer 0; the rows of the first
-    // group, phase (0, tb0) whole, the first half of phase (0, tb1) -- its second half sits in stages 0, 1 of k-step 0, as in every k-step ----
+    // ---- prologue: chunk 0 has landed (everything but chunk 1's 8 loads and the ring's last 4), its T images go to buffer 0; the columns
+    // of the first group, phase (0, tb0) whole, the first half of phase (0, tb1) -- its second half sits in stages 0, 1 of k-step 0, as in
+    // every k-step ----
     asm volatile("s_waitcnt vmcnt(%8)"
                  : "+v"(first[0]), "+v"(first[1]), "+v"(first[2]), "+v"(first[3]), "+v"(first[4]), "+v"(first[5]), "+v"(first[6]), "+v"(first[7])
                  : "n"(W4_NP + 4));  // all but chunk 1 and the ring's l = 2
 #pragma unroll
-    for (int i = 0; i < W4_NP; i++) store_piece(first, wdst, i);
+    for (int u = 0; u < 16; u++) t_unit(first, wdst, u);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    read_row(pa, 0, 0, 0, 0);
-    read_row(pb, 1, 0, 0, 0);
+    read_group(tbuf[0], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 24; j++) slot(0, 0, j);
 #pragma unroll
@@ -346,9 +365,7 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
                 // waited for since).  Behind the barrier chunk c + 1 is everybody's and chunk c's buffer takes chunk c + 2
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-                for (int X = 0; X < 2; X++)
-#pragma unroll
-                    for (int k = 0; k < 3; k++) cur[X][k] += bufstep;
+                for (int k = 0; k < 3; k++) cur[k] += bufstep;
                 bufstep = -bufstep;
             }
             if (first_use) {
@@ -378,11 +395,8 @@ __device__ __forceinline__ void w4_layer(const float* __restrict__ in, const _Fl
                 __builtin_amdgcn_sched_barrier(0);
                 slot(ph == 1 ? SP_ : SP_ ^ 1, ph == 2 ? 0 : 1, j);
                 // stage 4 of the even k-step: the pending chunk into the buffer the last chunk change left (two pieces per gap)
-                if (SP_ == 0 && i == 4 && e < 4) {
-                    const uint32_t target = wdst + (uint32_t)(bufstep > 0 ? W4_DBUF : 0);
-                    store_piece(pend, target, 2 * e);
-                    store_piece(pend, target, 2 * e + 1);
-                }
+                // stages 4, 5, 6 of the even k-step: the pending chunk's sixteen T units into the buffer the last chunk change left, one per gap
+                if (SP_ == 0 && i >= 4 && 6 * (i - 4) + e < 16) t_unit(pend, wdst + (uint32_t)(bufstep > 0 ? W4_DBUF : 0), 6 * (i - 4) + e);
                 // this gap's load
                 const int le = (i & 1) ? e : e - 2;
                 if (le >= 0 && le < 4) {
