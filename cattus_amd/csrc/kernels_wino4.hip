@@ -10,18 +10,20 @@
 //   U: the same buffer and fragment order as K1w ([cout / 32][k-step x 16 + f][hi | lo][lane][8 f16]); a wave streams ITS four
 //       frequencies of its two cout blocks: 1 MB per CU and layer, half of K1w's, each byte of it loaded by exactly one wave
 //   V = B^T d B IN REGISTERS, in MFMA operand layout: lane (tile n, k-half h) needs row q of B^T d B for channels 8h..8h+7 of
-//       its own tile -- two patch rows (B^T row q combines two), four columns -- read straight from the activation chunk in LDS
-//       (ds_read_b128, 4 channels), combined in f32 (the order of K1w: rows first, then columns), split into (hi, lo) and
-//       written into the registers the MFMAs read.  No V image, no V write, no V fragment read, no barrier for V; the four waves
-//       do the same number of additions in total as K1w's shared transform (each does one row of the four).
-//   d: 32-channel chunks of the 256 pixel rows, global -> registers -> LDS (8 + 8 per thread and chunk), two images per buffer (one
-//       per tile block, K1w's layout: pixel pitch 144 B, 64 B per board row, zero area for off-board patch pixels, and the second
-//       board one 16-B piece to the right: with 32 DIFFERENT tiles per half wave that is what keeps the four 16-lane groups of a
-//       ds_read_b128 on 16 different bank slots)
+//       its own tile -- the row combination t = d[ra] +- d[rb] of its four patch columns (read from LDS, ds_read_b128, 4 channels),
+//       combined across the columns in f32 (the order of K1w: rows first, then columns), split into (hi, lo) and written into the
+//       registers the MFMAs read.  No V image, no V write, no V fragment read, no barrier for V.
+//   d: 32-channel chunks of the 256 pixel rows, global -> registers -> LDS -- and on the way ROW-COMBINED: wave q fetches board q, a
+//       thread all eight rows of one column (8 loads per thread and chunk), forms the 4 frequency rows x 4 tile rows = 16 values t of
+//       its column (neighbouring tiles share two of their four columns: 128 distinct values per board and channel where the tiles
+//       would compute 256) and stores one image PER FREQUENCY ROW; wave q reads its own.  Layout [frequency row][tile block][board,
+//       tile row][column]: pixel pitch 144 B (9 sixteen-byte slots), row pitch 72 slots = 8 mod 16, the second board one slot to the
+//       right, a zero area behind each image for patch columns off the board -- found by enumeration over the lane groups of
+//       ds_read_b128: with 32 DIFFERENT tiles per half wave that keeps the 16 lanes of every group on 16 different bank slots
 //   per k-step (16 channels) a wave issues 48 MFMAs (as K1w), 16 + 4 global_load_dwordx4 (K1w: 32) -- ONE PER MFMA GAP, never in a
-//       row -- and 32 ds_read_b128 in bursts of four, between which sit ~290 VALU instructions of transform: per V value a row
-//       combination, a column combination, half a conversion for the hi half, an f32 difference and half a conversion for the lo
-//       half (17 issue cycles; scripts/probes/gap_cost_probe.hip prices every one of them: the loop is the sum of its issue costs)
+//       row -- and 16 ds_read_b128 in bursts of four, between which sit ~225 VALU instructions of transform: per V value a column
+//       combination, half a conversion for the hi half, an f32 difference and half a conversion for the lo half, and per chunk the
+//       row combinations (scripts/probes/gap_cost_probe.hip prices every one of them: the loop is the sum of its issue costs)
 //   stage order of a k-step: (tb0,l0) (tb0,l1) (tb1,l0) (tb1,l1) (tb0,l2) (tb0,l3) (tb1,l2) (tb1,l3): a U stage (4 loads, 16
 //       registers) lives for three stages, is refilled in the gaps of the stage behind its last use and has five stages to land -- a
 //       ring of ONE k-step (64 registers); V of k-step s+1 is made in 24-gap phases (tb0: stages 2-5 of k-step s, tb1: stages 6-7 and
