@@ -32,6 +32,9 @@ EDITS = {
     "skew64": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) __builtin_amdgcn_s_sleep(1);\n                if (q >= 2) __builtin_amdgcn_s_sleep(1);\n                if (q >= 3) __builtin_amdgcn_s_sleep(1);\n#pragma unroll", 1))],
     "skew32": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n                if (q >= 2) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n                if (q >= 3) asm volatile(\"s_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\\n\\ts_nop 7\");\n#pragma unroll", 1))],
     "skew128": [(SKEW_ANCHOR, SKEW_ANCHOR.replace("#pragma unroll", "if (q >= 1) __builtin_amdgcn_s_sleep(2);\n                if (q >= 2) __builtin_amdgcn_s_sleep(2);\n                if (q >= 3) __builtin_amdgcn_s_sleep(2);\n#pragma unroll", 1))],
+    # an even stage's loads in its light gaps (0: the group's wait, 1 and 3: nothing of the transform) instead of gaps 2-5 (results stay right)
+    "lightgaps": [("                const int le = (i & 1) ? e : e - 2;\n", "                const int le = (i & 1) ? e : e == 0 ? 0 : e == 1 ? 1 : e == 3 ? 2 : e == 5 ? 3 : -1;\n")],
+    "lightgaps2": [("                const int le = (i & 1) ? e : e - 2;\n", "                const int le = (i & 1) ? e : e == 1 ? 0 : e == 3 ? 1 : e == 4 ? 2 : e == 5 ? 3 : -1;\n")],
     "sleep1": [("                __builtin_amdgcn_s_sleep(8);\n", "                __builtin_amdgcn_s_sleep(1);\n")],
     "sleep0": [("                __builtin_amdgcn_s_sleep(8);\n", "")],
     "nodma": [("                issue_chunk(ch_next, freed);\n", "")],
